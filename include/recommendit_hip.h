@@ -1,0 +1,162 @@
+/* recommendit_hip.h -- C ABI of librecommendit_hip.so (gfx950 / MI355X).
+ *
+ * The reference (sarihammad/recommendit) has no FFI of its own: its seam is three Python
+ * classes (src/models/__init__.py:1-3).  Each entry point below names the reference code
+ * whose *body* it replaces (paths relative to the reference root); the Python classes in
+ * recommendit_amd/ keep the reference's class surface and call these through ctypes.
+ * INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 (RIHIP_OK) or a non-zero status; rihip_last_error() gives the
+ *     message (thread-local).  Nothing aborts the process: the callers' fallbacks
+ *     (src/serving/recommender.py:202-207, src/serving/app.py:182-185) must keep working.
+ *   - all array pointers are DEVICE pointers unless a comment says host; the caller allocates
+ *     inputs, outputs and workspaces; the library never frees caller memory and never keeps a
+ *     caller pointer after returning.  Opaque handles (ip_index, gbdt) own their device memory
+ *     and are destroyed by their paired *_destroy.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are
+ *     asynchronous on that stream except where documented.
+ *   - float = IEEE binary32, ids/rows = int64_t.
+ */
+#ifndef RECOMMENDIT_HIP_H
+#define RECOMMENDIT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RIHIP_ABI_VERSION 1
+
+int rihip_abi_version(void);
+/* "gfx950": the only ISA this library carries code objects for */
+const char* rihip_target_arch(void);
+/* last error message of the calling thread ("" if none) */
+const char* rihip_last_error(void);
+/* name of device 0's ISA as reported by the runtime (host buffer); needs a GPU */
+int rihip_device_arch(char* buf, int buf_len);
+
+/* ---- Two-Tower towers ----------------------------------------------------------------------
+ * rihip_tower_forward replaces UserTower.forward (src/models/two_tower.py:39-42; genres==NULL)
+ * and ItemTower.forward (:68-72; genres = [B,18] multi-hot):
+ *   x = table[ids] (|| genres) ; h = dropout(relu(x W1^T + b1)) ; y = h W2^T + b2 ;
+ *   out = y / max(|y|_2, 1e-12).
+ * table [n_rows,d]; W1 [hidden, d(+18)]; b1 [hidden]; W2 [d,hidden]; b2 [d]  (nn.Linear layout).
+ * training!=0 && dropout_p>0: keep-mask from the counter-based generator keyed by
+ * (seed, (row0+row)*hidden+col) -- see oracle/two_tower_np.py:dropout_keep_mask.
+ * hid [B,hidden] (post-dropout activations) and denom [B] are saved for backward (nullable).
+ * err_flag (device int, nullable) is set to 1 if an id is outside [0,n_rows) (row 0 is used).
+ * Supported (d,hidden): see rihip_tower_supported. */
+int rihip_tower_supported(int d, int hidden);
+int rihip_tower_forward(const float* table, int64_t n_rows, const int64_t* ids, const float* genres, int64_t B,
+                        int d, int hidden, const float* W1, const float* b1, const float* W2, const float* b2,
+                        int training, float dropout_p, uint64_t seed, int64_t row0, float* out, float* hid,
+                        float* denom, int* err_flag, void* stream);
+
+/* Backward of the above (autograd of two_tower.py:39-42/:68-72, run by
+ * src/training/train_embeddings.py:190).  grad_out = dL/d out [B,d].
+ * Outputs: dX [B,d] per-sample embedding-row gradients (scatter them with
+ * rihip_embedding_scatter_add or the row-sparse path); dW1/db1/dW2/db2 in nn.Linear layout,
+ * overwritten (accumulate=0) or added to (accumulate=1).  dropout_scale = 1/(1-p) if the
+ * forward ran in training mode with p>0, else 1.  workspace: floats, size from
+ * rihip_tower_backward_workspace_floats. */
+int64_t rihip_tower_backward_workspace_floats(int64_t B, int d, int hidden, int item);
+int rihip_tower_backward(const float* table, int64_t n_rows, const int64_t* ids, const float* genres, int64_t B,
+                         int d, int hidden, const float* W1, const float* W2, const float* grad_out,
+                         const float* out, const float* denom, const float* hid, float dropout_scale, float* dX,
+                         float* dW1, float* db1, float* dW2, float* db2, int accumulate, float* workspace,
+                         void* stream);
+
+/* nn.Embedding backward (dense): grad_table[ids[b]] += dX[b]; row 0 (padding_idx, two_tower.py:27,54) skipped */
+int rihip_embedding_scatter_add(float* grad_table, int64_t n_rows, const int64_t* ids, const float* dX, int64_t B,
+                                int d, void* stream);
+
+/* ---- losses --------------------------------------------------------------------------------
+ * rihip_bpr_pair_loss replaces TwoTowerModel.bpr_loss (two_tower.py:117-130) and its backward:
+ * loss = mean softplus(-(u.p - u.n)); dU,dP,dN = d loss / d inputs.  workspace: >=1024 doubles. */
+int rihip_bpr_pair_loss(const float* U, const float* P, const float* N, int64_t B, int d, float* loss, float* dU,
+                        float* dP, float* dN, double* workspace, void* stream);
+
+/* In-batch-negative BPR (TwoTowerModel.in_batch_bpr_loss, two_tower.py:132-160, closed form
+ *   L = 1/(B(B-1)) sum_i sum_{j!=i} softplus(s_ij - s_ii)) is three calls:
+ *   rihip_rowdot        pos[i] = U[i].I[i+i_offset]
+ *   rihip_inbatch_sweep mode_user=1: owners=users, swept=items -> d_owner=dU, r_out, loss_part
+ *   rihip_inbatch_sweep mode_user=0: owners=items, swept=users (+pos, r_in=r) -> d_owner=dI
+ *   rihip_sum_partials  loss = scale * sum(loss_part)   with scale = 1/(B(B-1))
+ * Global indices (owner_goff / swept_goff) place a rank's local rows inside the all-gathered
+ * batch for multi-GPU in-batch negatives; n_global = B.  d in {32,64,128}. */
+int rihip_rowdot(const float* U, const float* I, int64_t B, int64_t i_offset, int d, float* pos, void* stream);
+int64_t rihip_inbatch_workspace_doubles(int64_t n_owner);
+int rihip_inbatch_sweep(int mode_user, const float* owners, int64_t n_owner, int64_t owner_goff, const float* swept,
+                        int64_t n_swept, int64_t swept_goff, int d, const float* pos, const float* r_in,
+                        int64_t n_global, float* d_owner, float* r_out, double* loss_part, void* stream);
+int rihip_sum_partials(const double* part, int64_t n, double scale, float* out, void* stream);
+
+/* ---- optimiser -----------------------------------------------------------------------------
+ * clip_grad_norm_(max_norm) (train_embeddings.py:191): rihip_sumsq writes rihip_sumsq_nparts()
+ * partial sums of x^2 per call; rihip_clip_coef reduces any number of partials to
+ * coef = min(1, max_norm/(norm+1e-6)) ON DEVICE (no host sync), consumed by the Adam kernels. */
+int rihip_sumsq_nparts(void);
+int rihip_sumsq(const float* x, int64_t n, double* part, void* stream);
+int rihip_clip_coef(const double* part, int64_t n_part, float max_norm, float* coef, float* total_norm, void* stream);
+/* torch.optim.Adam(lr, betas, eps, weight_decay) single step with coupled L2
+ * (train_embeddings.py:160,192); g is scaled by *clip_coef (nullable) first.  step >= 1. */
+int rihip_adam_dense(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, int64_t step, const float* clip_coef, void* stream);
+
+/* Row-sparse path for tables too large for a dense pass per step (SURVEY.md §7 hard part 1):
+ * group (id,sample) pairs by id (radix sort), sum each row's contributions in sorted order
+ * (bitwise reproducible), then Adam on touched rows only.  workspace bytes from
+ * rihip_rows_workspace_bytes(B); uniq int64[B]; Gc float[B,d]; part double[rihip_rows_nparts()]. */
+int64_t rihip_rows_workspace_bytes(int64_t B);
+int rihip_rows_nparts(void);
+int rihip_rows_group(const int64_t* ids, int64_t B, int64_t* uniq, void* workspace, int64_t workspace_bytes,
+                     void* stream);
+int rihip_rows_n_unique_ptr(void* workspace, int64_t B, const int** n_unique_dev);
+int rihip_rows_reduce(const float* dX, int64_t B, int d, const int64_t* uniq, void* workspace, float* Gc,
+                      double* part, void* stream);
+int rihip_adam_rows(float* table, float* m, float* v, const int64_t* uniq, const float* Gc, int64_t B, int d,
+                    void* workspace, float lr, float beta1, float beta2, float eps, float weight_decay,
+                    int64_t step, const float* clip_coef, void* stream);
+
+/* ---- inner-product index -------------------------------------------------------------------
+ * Replaces faiss.IndexFlatIP / IndexIVFFlat(METRIC_INNER_PRODUCT) behind FAISSIndex
+ * (src/models/faiss_index.py:68-74 build, :113/:145 search, :164/:196 write/read).
+ * Normalisation of vectors/queries stays in the wrapper (faiss_index.py:64-65,:108-110).
+ * search: Q device [nq,d]; out_scores f32[nq,k] descending, -inf padded; out_rows i64[nq,k]
+ * row numbers in insertion order, -1 padded (faiss convention kept by faiss_index.py:148-152).
+ * Exact for a flat index (ties -> lowest row); synchronises the stream once per 4096 queries
+ * (exactness check).  k <= rihip_ip_index_max_k().  d in {32,64,128}. */
+int rihip_ip_index_create(int d, void** handle);
+int rihip_ip_index_destroy(void* handle);
+int rihip_ip_index_set_vectors(void* handle, const float* X, int64_t N, int x_on_device, void* stream);
+int64_t rihip_ip_index_ntotal(void* handle);
+int rihip_ip_index_is_ivf(void* handle);
+int rihip_ip_index_max_k(void);
+int rihip_ip_index_train_ivf(void* handle, int nlist, int n_iter, uint64_t seed, void* stream);
+int rihip_ip_index_set_nprobe(void* handle, int nprobe);
+int rihip_ip_index_search(void* handle, const float* Q, int64_t nq, int k, float* out_scores, int64_t* out_rows,
+                          void* stream);
+int rihip_ip_index_save(void* handle, const char* path);          /* host path; synchronous */
+int rihip_ip_index_load(const char* path, void** handle);         /* host path; synchronous */
+/* rows[i] = rows[i] >= 0 ? item_ids[rows[i]] : -1   (faiss_index.py:123, :148-152) */
+int rihip_map_rows_to_ids(int64_t* rows, int64_t n, const int64_t* item_ids, void* stream);
+
+/* ---- LambdaMART forward --------------------------------------------------------------------
+ * Replaces lgb.Booster(model_file=...) (src/models/ranker.py:219) and Booster.predict
+ * (ranker.py:174): raw score = sum over trees of the reached leaf value, float64.
+ * X device f32 [n, ldx]; out device f64 [n]. */
+int rihip_gbdt_load_text(const char* path, void** handle);
+int rihip_gbdt_create_from_text(const char* text, int64_t len, void** handle);
+int rihip_gbdt_destroy(void* handle);
+int rihip_gbdt_num_trees(void* handle);
+int rihip_gbdt_num_features(void* handle);
+int64_t rihip_gbdt_feature_names(void* handle, char* buf, int64_t buf_len); /* '\n'-joined, host */
+int rihip_gbdt_feature_importance(void* handle, int importance_type, double* out_host);
+int rihip_gbdt_predict(void* handle, const float* X, int64_t n, int ldx, double* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RECOMMENDIT_HIP_H */

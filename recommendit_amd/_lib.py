@@ -1,0 +1,132 @@
+"""ctypes binding of librecommendit_hip.so (the C ABI declared in include/recommendit_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (or ``make -C recommendit_amd/csrc``).
+There is NO CPU fallback: if the library is missing, ``lib()`` raises ImportError; if no HIP
+device is visible, every compute entry raises RuntimeError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+from typing import Optional
+
+import torch
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "librecommendit_hip.so"
+_lib: Optional[C.CDLL] = None
+
+c_f32p = C.c_void_p
+c_i64 = C.c_int64
+vp = C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/recommendit_hip.h one-to-one
+SIGNATURES = {
+    "rihip_abi_version": (C.c_int, []),
+    "rihip_target_arch": (C.c_char_p, []),
+    "rihip_last_error": (C.c_char_p, []),
+    "rihip_device_arch": (C.c_int, [C.c_char_p, C.c_int]),
+    "rihip_tower_supported": (C.c_int, [C.c_int, C.c_int]),
+    "rihip_tower_forward": (C.c_int, [vp, c_i64, vp, vp, c_i64, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, C.c_float,
+                                      C.c_uint64, c_i64, vp, vp, vp, vp, vp]),
+    "rihip_tower_backward_workspace_floats": (c_i64, [c_i64, C.c_int, C.c_int, C.c_int]),
+    "rihip_tower_backward": (C.c_int, [vp, c_i64, vp, vp, c_i64, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_float,
+                                       vp, vp, vp, vp, vp, C.c_int, vp, vp]),
+    "rihip_embedding_scatter_add": (C.c_int, [vp, c_i64, vp, vp, c_i64, C.c_int, vp]),
+    "rihip_bpr_pair_loss": (C.c_int, [vp, vp, vp, c_i64, C.c_int, vp, vp, vp, vp, vp, vp]),
+    "rihip_rowdot": (C.c_int, [vp, vp, c_i64, c_i64, C.c_int, vp, vp]),
+    "rihip_inbatch_workspace_doubles": (c_i64, [c_i64]),
+    "rihip_inbatch_sweep": (C.c_int, [C.c_int, vp, c_i64, c_i64, vp, c_i64, c_i64, C.c_int, vp, vp, c_i64, vp, vp, vp,
+                                      vp]),
+    "rihip_sum_partials": (C.c_int, [vp, c_i64, C.c_double, vp, vp]),
+    "rihip_sumsq_nparts": (C.c_int, []),
+    "rihip_sumsq": (C.c_int, [vp, c_i64, vp, vp]),
+    "rihip_clip_coef": (C.c_int, [vp, c_i64, C.c_float, vp, vp, vp]),
+    "rihip_adam_dense": (C.c_int, [vp, vp, vp, vp, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, c_i64,
+                                   vp, vp]),
+    "rihip_rows_workspace_bytes": (c_i64, [c_i64]),
+    "rihip_rows_nparts": (C.c_int, []),
+    "rihip_rows_group": (C.c_int, [vp, c_i64, vp, vp, c_i64, vp]),
+    "rihip_rows_n_unique_ptr": (C.c_int, [vp, c_i64, C.POINTER(vp)]),
+    "rihip_rows_reduce": (C.c_int, [vp, c_i64, C.c_int, vp, vp, vp, vp, vp]),
+    "rihip_adam_rows": (C.c_int, [vp, vp, vp, vp, vp, c_i64, C.c_int, vp, C.c_float, C.c_float, C.c_float, C.c_float,
+                                  C.c_float, c_i64, vp, vp]),
+    "rihip_ip_index_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+    "rihip_ip_index_destroy": (C.c_int, [vp]),
+    "rihip_ip_index_set_vectors": (C.c_int, [vp, vp, c_i64, C.c_int, vp]),
+    "rihip_ip_index_ntotal": (c_i64, [vp]),
+    "rihip_ip_index_is_ivf": (C.c_int, [vp]),
+    "rihip_ip_index_max_k": (C.c_int, []),
+    "rihip_ip_index_train_ivf": (C.c_int, [vp, C.c_int, C.c_int, C.c_uint64, vp]),
+    "rihip_ip_index_set_nprobe": (C.c_int, [vp, C.c_int]),
+    "rihip_ip_index_search": (C.c_int, [vp, vp, c_i64, C.c_int, vp, vp, vp]),
+    "rihip_ip_index_save": (C.c_int, [vp, C.c_char_p]),
+    "rihip_ip_index_load": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
+    "rihip_map_rows_to_ids": (C.c_int, [vp, c_i64, vp, vp]),
+    "rihip_gbdt_load_text": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
+    "rihip_gbdt_create_from_text": (C.c_int, [C.c_char_p, c_i64, C.POINTER(vp)]),
+    "rihip_gbdt_destroy": (C.c_int, [vp]),
+    "rihip_gbdt_num_trees": (C.c_int, [vp]),
+    "rihip_gbdt_num_features": (C.c_int, [vp]),
+    "rihip_gbdt_feature_names": (c_i64, [vp, C.c_char_p, c_i64]),
+    "rihip_gbdt_feature_importance": (C.c_int, [vp, C.c_int, vp]),
+    "rihip_gbdt_predict": (C.c_int, [vp, vp, c_i64, C.c_int, vp, vp]),
+}
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the HIP library; ImportError if it was never built."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C recommendit_amd/csrc`. recommendit_amd has no CPU fallback."
+            )
+        l = C.CDLL(str(LIB_PATH), mode=os.RTLD_GLOBAL if hasattr(os, "RTLD_GLOBAL") else C.DEFAULT_MODE)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError here == header/library drift
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+class RihipError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().rihip_last_error().decode("utf-8", "replace")
+        raise RihipError(f"{what or 'recommendit_hip'} failed (status {rc}): {msg}")
+
+
+def have_gpu() -> bool:
+    return torch.cuda.is_available()
+
+
+def device() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("recommendit_amd: no HIP device visible (the product path has no CPU fallback)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def f32c(t: torch.Tensor) -> torch.Tensor:
+    """contiguous float32 view/copy on the HIP device"""
+    return t.to(device=device(), dtype=torch.float32).contiguous()
+
+
+def i64c(t: torch.Tensor) -> torch.Tensor:
+    return t.to(device=device(), dtype=torch.int64).contiguous()

@@ -1,0 +1,94 @@
+// Shared device/host helpers for the recommendit gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define RIHIP_OK 0
+#define RIHIP_ERR_ARG 1
+#define RIHIP_ERR_HIP 2
+#define RIHIP_ERR_SHAPE 3
+#define RIHIP_ERR_IO 4
+#define RIHIP_ERR_STATE 5
+
+void rihip_set_error(const char* fmt, ...);
+
+#define RIHIP_CHECK_HIP(expr)                                                          \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess) {                                                            \
+      rihip_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return RIHIP_ERR_HIP;                                                            \
+    }                                                                                  \
+  } while (0)
+
+#define RIHIP_CHECK_LAUNCH()                                                           \
+  do {                                                                                 \
+    hipError_t _e = hipGetLastError();                                                 \
+    if (_e != hipSuccess) {                                                            \
+      rihip_set_error("%s:%d kernel launch -> %s", __FILE__, __LINE__, hipGetErrorString(_e)); \
+      return RIHIP_ERR_HIP;                                                            \
+    }                                                                                  \
+  } while (0)
+
+#define RIHIP_REQUIRE(cond, code, ...)                                                 \
+  do {                                                                                 \
+    if (!(cond)) {                                                                     \
+      rihip_set_error(__VA_ARGS__);                                                    \
+      return (code);                                                                   \
+    }                                                                                  \
+  } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define RIHIP_NCU 256
+
+// ---- exact-f32 MFMA 32x32x2: D[i][j] += sum_{k<2} A[i][k] B[k][j] -------------------
+// lane l supplies A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31]; accumulator register r of lane
+// l holds D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31].
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+// ---- counter-based dropout mask (bit-identical to oracle/two_tower_np.py) ----------
+__host__ __device__ __forceinline__ uint64_t rihip_splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x ^= x >> 30;
+  x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27;
+  x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return x;
+}
+// keep element `idx` (global row * n_cols + col) with probability 1-p; thresh24 = floor(p*2^24)
+__host__ __device__ __forceinline__ bool rihip_keep(uint64_t seed_mul, uint64_t idx, uint32_t thresh24) {
+  uint64_t h = rihip_splitmix64(idx ^ seed_mul);
+  return (uint32_t)(h >> 40) >= thresh24;
+}
+__host__ __device__ __forceinline__ uint64_t rihip_seed_mul(uint64_t seed) { return seed * 0xD1342543DE82EF95ull; }
+static inline uint32_t rihip_thresh24(float p) {
+  double t = (double)p * 16777216.0;
+  if (t < 0) t = 0;
+  if (t > 16777215.0) t = 16777215.0;
+  return (uint32_t)t;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

@@ -1,0 +1,359 @@
+// LambdaMART forward (sum of reached leaf values) for gfx950 -- replaces lgb.Booster.predict
+// behind LightGBMRanker.predict (reference src/models/ranker.py:161-174) and the text-model
+// loader behind LightGBMRanker.load (ranker.py:212-226).
+//
+// Neither HBM- nor MFMA-bound: the forest (<1 MB) is cache resident and each candidate chases
+// pointers.  Layout: the forest is cut into chunks of whole trees whose nodes fit LDS; a
+// workgroup = 64 candidates (one per lane, features staged TRANSPOSED in LDS so a lane's
+// feature fetch is bank = lane) x one tree chunk (nodes + leaves staged in LDS, 4 waves take
+// every 4th tree).  grid = (candidate tiles) x (chunks), so one 500-candidate request still
+// fills the chip.  Partial sums are combined in fixed order in double => deterministic.
+//
+// Decision rule restated from LightGBM (Tree::NumericalDecision / CategoricalDecision):
+//   numerical: NaN -> 0 unless missing_type==NaN; "missing" (zero|nan by type) goes default
+//   side; else left iff (double)fval <= threshold.  categorical: bitset membership.
+#include "common.h"
+#include "recommendit_hip.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct Node {  // 32 bytes
+  double thr;
+  int left, right;  // >=0 internal node (tree-local), <0 => ~leaf (tree-local)
+  int feat;
+  int dtype;        // LightGBM decision_type byte
+  int pad0, pad1;
+};
+
+constexpr int NODE_CAP = 1280;  // nodes per chunk staged in LDS (40 KB)
+constexpr int LEAF_CAP = 1536;  // leaves per chunk staged in LDS (12 KB)
+constexpr int F_MAX = 128;      // features staged per candidate tile (64 x F x 4 B <= 32 KB)
+
+struct Forest {
+  int n_trees = 0, n_features = 0;
+  std::vector<std::string> feature_names;
+  std::vector<double> imp_split, imp_gain;
+  bool average_output = false;
+  // host copies
+  std::vector<Node> nodes;
+  std::vector<double> leaves;
+  std::vector<int> tree_node_off, tree_leaf_off, tree_root;  // per tree (+1 sentinel for offs)
+  std::vector<int> chunk_tree_start;                         // [n_chunks+1]
+  std::vector<int> cat_boundaries, cat_words, tree_cat_b_off, tree_cat_w_off;
+  // device
+  Node* d_nodes = nullptr; double* d_leaves = nullptr;
+  int *d_tree_node_off = nullptr, *d_tree_leaf_off = nullptr, *d_tree_root = nullptr, *d_chunk = nullptr;
+  int *d_cat_b = nullptr, *d_cat_w = nullptr, *d_tree_cat_b_off = nullptr, *d_tree_cat_w_off = nullptr;
+  double* d_part = nullptr; int64_t part_elems = 0;
+};
+
+struct PredArgs {
+  const Node* nodes; const double* leaves;
+  const int *tree_node_off, *tree_leaf_off, *tree_root, *chunk;
+  const int *cat_b, *cat_w, *tree_cat_b_off, *tree_cat_w_off;
+  const float* X; int64_t n; int F; int ldx;
+  double* part;  // [n_chunks, n]
+};
+
+__device__ __forceinline__ bool decide_left(float fv, const Node& nd, const int* cat_b, const int* cat_w) {
+  double f = (double)fv;
+  const int dt = nd.dtype;
+  if (dt & 1) {  // categorical
+    if (isnan(f)) return false;
+    const int iv = (int)f;
+    if (iv < 0) return false;
+    const int ci = (int)nd.thr;
+    const int b0 = cat_b[ci], b1 = cat_b[ci + 1];
+    const int wi = iv >> 5;
+    if (wi >= b1 - b0) return false;
+    return (cat_w[b0 + wi] >> (iv & 31)) & 1;
+  }
+  const int missing = (dt >> 2) & 3;
+  const bool is_nan = isnan(f);
+  if (is_nan && missing != 2) f = 0.0;
+  const bool is_missing = (missing == 1) ? (fabs(f) <= 1e-35) : ((missing == 2) ? is_nan : false);
+  if (is_missing) return (dt & 2) != 0;
+  return f <= nd.thr;
+}
+
+__global__ __launch_bounds__(256) void gbdt_predict_kernel(PredArgs a) {
+  __shared__ __attribute__((aligned(16))) Node nS[NODE_CAP];
+  __shared__ double lS[LEAF_CAP];
+  __shared__ float xS[F_MAX * 64];  // transposed: xS[f*64 + lane]
+  __shared__ double red[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int chunk = blockIdx.y;
+  const int t0 = a.chunk[chunk], t1 = a.chunk[chunk + 1];
+  const int n0 = a.tree_node_off[t0], n1 = a.tree_node_off[t1];
+  const int l0 = a.tree_leaf_off[t0], l1 = a.tree_leaf_off[t1];
+  const bool in_lds = (n1 - n0) <= NODE_CAP && (l1 - l0) <= LEAF_CAP;
+  if (in_lds) {
+    const int4* src = reinterpret_cast<const int4*>(a.nodes + n0);
+    int4* dst = reinterpret_cast<int4*>(nS);
+    for (int i = tid; i < (n1 - n0) * 2; i += 256) dst[i] = src[i];
+    for (int i = tid; i < (l1 - l0); i += 256) lS[i] = a.leaves[l0 + i];
+  }
+  const int64_t row = (int64_t)blockIdx.x * 64 + lane;
+  for (int i = tid; i < 64 * a.F; i += 256) {
+    const int r = i / a.F, f = i % a.F;
+    const int64_t gr = (int64_t)blockIdx.x * 64 + r;
+    xS[f * 64 + r] = (gr < a.n) ? a.X[gr * a.ldx + f] : 0.f;
+  }
+  __syncthreads();
+  double acc = 0.0;
+  for (int t = t0 + w; t < t1; t += 4) {
+    const int nb = a.tree_node_off[t], lb = a.tree_leaf_off[t];
+    const Node* nodes = in_lds ? (nS + (nb - n0)) : (a.nodes + nb);
+    const int* cb = a.cat_b ? a.cat_b + a.tree_cat_b_off[t] : nullptr;
+    const int* cw = a.cat_w ? a.cat_w + a.tree_cat_w_off[t] : nullptr;
+    int node = a.tree_root[t];
+    while (node >= 0) {
+      const Node nd = nodes[node];
+      const float fv = xS[nd.feat * 64 + lane];
+      node = decide_left(fv, nd, cb, cw) ? nd.left : nd.right;
+    }
+    const int leaf = ~node;
+    acc += in_lds ? lS[lb - l0 + leaf] : a.leaves[lb + leaf];
+  }
+  red[w][lane] = acc;
+  __syncthreads();
+  if (w == 0 && row < a.n) a.part[(size_t)chunk * a.n + row] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+}
+
+__global__ void gbdt_reduce_kernel(const double* __restrict__ part, int n_chunks, int64_t n, double scale, double* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int c = 0; c < n_chunks; ++c) s += part[(size_t)c * n + i];
+  out[i] = s * scale;
+}
+
+// ---------------------------------- text-model parser -------------------------------------------
+bool split_kv(const std::string& ln, std::string* k, std::string* v) {
+  const size_t p = ln.find('=');
+  if (p == std::string::npos) return false;
+  *k = ln.substr(0, p);
+  *v = ln.substr(p + 1);
+  return true;
+}
+template <typename T>
+std::vector<T> parse_list(const std::string& s) {
+  std::vector<T> out;
+  std::istringstream is(s);
+  std::string tok;
+  while (is >> tok) {
+    if (sizeof(T) == sizeof(double)) out.push_back((T)strtod(tok.c_str(), nullptr));
+    else out.push_back((T)strtoll(tok.c_str(), nullptr, 10));
+  }
+  return out;
+}
+
+int parse_model(const std::string& text, Forest* F) {
+  std::istringstream in(text);
+  std::string ln, k, v;
+  bool in_tree = false, done = false;
+  struct RawTree {
+    int num_leaves = 0, num_cat = 0;
+    std::vector<long long> split_feature, decision_type, left, right, cat_b, cat_w;
+    std::vector<double> threshold, leaf_value, split_gain;
+  };
+  std::vector<RawTree> trees;
+  int max_feature_idx = -1;
+  while (!done && std::getline(in, ln)) {
+    while (!ln.empty() && (ln.back() == '\r' || ln.back() == ' ')) ln.pop_back();
+    if (ln.rfind("Tree=", 0) == 0) { trees.emplace_back(); in_tree = true; continue; }
+    if (ln == "end of trees") { done = true; break; }
+    if (!in_tree && ln == "average_output") { F->average_output = true; continue; }
+    if (!split_kv(ln, &k, &v)) continue;
+    if (!in_tree) {
+      if (k == "feature_names") { std::istringstream is(v); std::string t; while (is >> t) F->feature_names.push_back(t); }
+      else if (k == "max_feature_idx") max_feature_idx = atoi(v.c_str());
+      else if (k == "num_class") { if (atoi(v.c_str()) != 1) { rihip_set_error("gbdt: num_class=%s unsupported", v.c_str()); return RIHIP_ERR_SHAPE; } }
+      else if (k == "num_tree_per_iteration") { if (atoi(v.c_str()) != 1) { rihip_set_error("gbdt: num_tree_per_iteration=%s unsupported", v.c_str()); return RIHIP_ERR_SHAPE; } }
+    } else {
+      RawTree& t = trees.back();
+      if (k == "num_leaves") t.num_leaves = atoi(v.c_str());
+      else if (k == "num_cat") t.num_cat = atoi(v.c_str());
+      else if (k == "split_feature") t.split_feature = parse_list<long long>(v);
+      else if (k == "split_gain") t.split_gain = parse_list<double>(v);
+      else if (k == "threshold") t.threshold = parse_list<double>(v);
+      else if (k == "decision_type") t.decision_type = parse_list<long long>(v);
+      else if (k == "left_child") t.left = parse_list<long long>(v);
+      else if (k == "right_child") t.right = parse_list<long long>(v);
+      else if (k == "leaf_value") t.leaf_value = parse_list<double>(v);
+      else if (k == "cat_boundaries") t.cat_b = parse_list<long long>(v);
+      else if (k == "cat_threshold") t.cat_w = parse_list<long long>(v);
+      else if (k == "is_linear") { if (atoi(v.c_str()) != 0) { rihip_set_error("gbdt: linear trees unsupported"); return RIHIP_ERR_SHAPE; } }
+    }
+  }
+  if (trees.empty() && !done) { rihip_set_error("gbdt: no trees found (not a LightGBM text model?)"); return RIHIP_ERR_IO; }
+  F->n_trees = (int)trees.size();
+  F->n_features = max_feature_idx >= 0 ? max_feature_idx + 1 : (int)F->feature_names.size();
+  if ((int)F->feature_names.size() < F->n_features)
+    for (int i = (int)F->feature_names.size(); i < F->n_features; ++i) F->feature_names.push_back("Column_" + std::to_string(i));
+  F->imp_split.assign(F->n_features, 0.0);
+  F->imp_gain.assign(F->n_features, 0.0);
+  F->tree_node_off.push_back(0); F->tree_leaf_off.push_back(0);
+  F->tree_cat_b_off.clear(); F->tree_cat_w_off.clear();
+  bool any_cat = false;
+  for (auto& t : trees) {
+    const int ni = t.num_leaves > 1 ? t.num_leaves - 1 : 0;
+    if ((int)t.leaf_value.size() < (t.num_leaves > 0 ? t.num_leaves : 1) && !(t.num_leaves <= 1 && t.leaf_value.empty())) {
+      rihip_set_error("gbdt: tree with %d leaves has %zu leaf values", t.num_leaves, t.leaf_value.size()); return RIHIP_ERR_IO;
+    }
+    if (ni > 0 && ((int)t.split_feature.size() < ni || (int)t.threshold.size() < ni || (int)t.decision_type.size() < ni ||
+                   (int)t.left.size() < ni || (int)t.right.size() < ni)) {
+      rihip_set_error("gbdt: truncated tree arrays"); return RIHIP_ERR_IO;
+    }
+    F->tree_cat_b_off.push_back((int)F->cat_boundaries.size());
+    F->tree_cat_w_off.push_back((int)F->cat_words.size());
+    for (auto x : t.cat_b) F->cat_boundaries.push_back((int)x);
+    for (auto x : t.cat_w) F->cat_words.push_back((int)x);
+    if (t.num_cat > 0) any_cat = true;
+    F->tree_root.push_back(ni > 0 ? 0 : ~0);
+    for (int i = 0; i < ni; ++i) {
+      Node nd;
+      memset(&nd, 0, sizeof(nd));
+      nd.thr = t.threshold[i]; nd.left = (int)t.left[i]; nd.right = (int)t.right[i];
+      nd.feat = (int)t.split_feature[i]; nd.dtype = (int)t.decision_type[i];
+      if (nd.feat < 0 || nd.feat >= F->n_features) { rihip_set_error("gbdt: split_feature %d out of range", nd.feat); return RIHIP_ERR_IO; }
+      if ((nd.left >= ni) || (nd.right >= ni) || (~nd.left >= t.num_leaves && nd.left < 0) || (~nd.right >= t.num_leaves && nd.right < 0)) {
+        rihip_set_error("gbdt: child index out of range"); return RIHIP_ERR_IO;
+      }
+      F->nodes.push_back(nd);
+      F->imp_split[nd.feat] += 1.0;
+      if (i < (int)t.split_gain.size()) F->imp_gain[nd.feat] += t.split_gain[i];
+    }
+    if (t.leaf_value.empty()) F->leaves.push_back(0.0);
+    else for (int i = 0; i < (t.num_leaves > 0 ? t.num_leaves : 1); ++i) F->leaves.push_back(t.leaf_value[i]);
+    F->tree_node_off.push_back((int)F->nodes.size());
+    F->tree_leaf_off.push_back((int)F->leaves.size());
+  }
+  if (!any_cat) { F->cat_boundaries.clear(); F->cat_words.clear(); }
+  // chunks of whole trees that fit the LDS staging budget (an oversize tree gets its own chunk, read from L2)
+  F->chunk_tree_start.push_back(0);
+  int cn = 0, cl = 0, ct = 0;
+  for (int t = 0; t < F->n_trees; ++t) {
+    const int tn = F->tree_node_off[t + 1] - F->tree_node_off[t], tl = F->tree_leaf_off[t + 1] - F->tree_leaf_off[t];
+    if (ct > 0 && (cn + tn > NODE_CAP || cl + tl > LEAF_CAP || ct >= 16)) { F->chunk_tree_start.push_back(t); cn = cl = ct = 0; }
+    cn += tn; cl += tl; ++ct;
+  }
+  F->chunk_tree_start.push_back(F->n_trees);
+  return RIHIP_OK;
+}
+
+template <typename T>
+int upload(const std::vector<T>& v, T** d) {
+  *d = nullptr;
+  if (v.empty()) return RIHIP_OK;
+  if (hipMalloc((void**)d, sizeof(T) * v.size()) != hipSuccess || hipMemcpy(*d, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice) != hipSuccess) {
+    rihip_set_error("gbdt: device upload failed"); return RIHIP_ERR_HIP;
+  }
+  return RIHIP_OK;
+}
+
+void destroy_forest(Forest* F) {
+  if (!F) return;
+  hipFree(F->d_nodes); hipFree(F->d_leaves); hipFree(F->d_tree_node_off); hipFree(F->d_tree_leaf_off); hipFree(F->d_tree_root);
+  hipFree(F->d_chunk); hipFree(F->d_cat_b); hipFree(F->d_cat_w); hipFree(F->d_tree_cat_b_off); hipFree(F->d_tree_cat_w_off);
+  hipFree(F->d_part);
+  delete F;
+}
+
+}  // namespace
+
+extern "C" int rihip_gbdt_create_from_text(const char* text, int64_t len, void** handle) {
+  RIHIP_REQUIRE(text && len > 0 && handle, RIHIP_ERR_ARG, "gbdt_create_from_text: bad arguments");
+  Forest* F = new Forest();
+  int rc = parse_model(std::string(text, (size_t)len), F);
+  if (rc == RIHIP_OK && F->n_features > F_MAX) { rihip_set_error("gbdt: %d features > %d supported", F->n_features, F_MAX); rc = RIHIP_ERR_SHAPE; }
+  if (rc == RIHIP_OK && F->n_trees > 0) {
+    std::vector<Node> nodes = F->nodes;
+    if (nodes.empty()) { Node z; memset(&z, 0, sizeof(z)); nodes.push_back(z); }
+    rc = upload(nodes, &F->d_nodes);
+    if (!rc) rc = upload(F->leaves, &F->d_leaves);
+    if (!rc) rc = upload(F->tree_node_off, &F->d_tree_node_off);
+    if (!rc) rc = upload(F->tree_leaf_off, &F->d_tree_leaf_off);
+    if (!rc) rc = upload(F->tree_root, &F->d_tree_root);
+    if (!rc) rc = upload(F->chunk_tree_start, &F->d_chunk);
+    if (!rc && !F->cat_boundaries.empty()) {
+      rc = upload(F->cat_boundaries, &F->d_cat_b);
+      if (!rc) rc = upload(F->cat_words, &F->d_cat_w);
+      if (!rc) rc = upload(F->tree_cat_b_off, &F->d_tree_cat_b_off);
+      if (!rc) rc = upload(F->tree_cat_w_off, &F->d_tree_cat_w_off);
+    }
+  }
+  if (rc != RIHIP_OK) { destroy_forest(F); return rc; }
+  *handle = F;
+  return RIHIP_OK;
+}
+
+extern "C" int rihip_gbdt_load_text(const char* path, void** handle) {
+  RIHIP_REQUIRE(path && handle, RIHIP_ERR_ARG, "gbdt_load_text: bad arguments");
+  std::ifstream f(path, std::ios::binary);
+  RIHIP_REQUIRE(f.good(), RIHIP_ERR_IO, "gbdt_load_text: cannot open %s", path);
+  std::stringstream ss;
+  ss << f.rdbuf();
+  const std::string s = ss.str();
+  RIHIP_REQUIRE(!s.empty(), RIHIP_ERR_IO, "gbdt_load_text: %s is empty", path);
+  return rihip_gbdt_create_from_text(s.data(), (int64_t)s.size(), handle);
+}
+
+extern "C" int rihip_gbdt_destroy(void* handle) { destroy_forest((Forest*)handle); return RIHIP_OK; }
+extern "C" int rihip_gbdt_num_trees(void* handle) { return handle ? ((Forest*)handle)->n_trees : 0; }
+extern "C" int rihip_gbdt_num_features(void* handle) { return handle ? ((Forest*)handle)->n_features : 0; }
+
+// feature names joined by '\n' into buf (returns needed length incl. NUL)
+extern "C" int64_t rihip_gbdt_feature_names(void* handle, char* buf, int64_t buf_len) {
+  Forest* F = (Forest*)handle;
+  if (!F) return 0;
+  std::string s;
+  for (size_t i = 0; i < F->feature_names.size(); ++i) { if (i) s += '\n'; s += F->feature_names[i]; }
+  if (buf && buf_len > 0) { const size_t n = s.size() < (size_t)buf_len - 1 ? s.size() : (size_t)buf_len - 1; memcpy(buf, s.data(), n); buf[n] = 0; }
+  return (int64_t)s.size() + 1;
+}
+
+// importance_type: 0 = split count, 1 = total gain; out[n_features]
+extern "C" int rihip_gbdt_feature_importance(void* handle, int importance_type, double* out) {
+  Forest* F = (Forest*)handle;
+  RIHIP_REQUIRE(F && out, RIHIP_ERR_ARG, "gbdt_feature_importance: bad arguments");
+  const std::vector<double>& v = importance_type == 0 ? F->imp_split : F->imp_gain;
+  for (int i = 0; i < F->n_features; ++i) out[i] = v[i];
+  return RIHIP_OK;
+}
+
+// X: device f32 [n, ldx] (first n_features columns used); out: device f64 [n] raw scores
+extern "C" int rihip_gbdt_predict(void* handle, const float* X, int64_t n, int ldx, double* out, void* stream) {
+  Forest* F = (Forest*)handle;
+  RIHIP_REQUIRE(F && X && out && n >= 0, RIHIP_ERR_ARG, "gbdt_predict: bad arguments");
+  RIHIP_REQUIRE(ldx >= F->n_features, RIHIP_ERR_SHAPE, "gbdt_predict: %d feature columns given, model needs %d", ldx, F->n_features);
+  if (n == 0) return RIHIP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (F->n_trees == 0) { RIHIP_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(double) * n, st)); return RIHIP_OK; }
+  const int n_chunks = (int)F->chunk_tree_start.size() - 1;
+  if (F->part_elems < (int64_t)n_chunks * n) {
+    if (F->d_part) hipFree(F->d_part);
+    F->d_part = nullptr; F->part_elems = 0;
+    RIHIP_CHECK_HIP(hipMalloc((void**)&F->d_part, sizeof(double) * (size_t)n_chunks * n));
+    F->part_elems = (int64_t)n_chunks * n;
+  }
+  PredArgs a;
+  a.nodes = F->d_nodes; a.leaves = F->d_leaves; a.tree_node_off = F->d_tree_node_off; a.tree_leaf_off = F->d_tree_leaf_off;
+  a.tree_root = F->d_tree_root; a.chunk = F->d_chunk; a.cat_b = F->d_cat_b; a.cat_w = F->d_cat_w;
+  a.tree_cat_b_off = F->d_tree_cat_b_off; a.tree_cat_w_off = F->d_tree_cat_w_off;
+  a.X = X; a.n = n; a.F = F->n_features; a.ldx = ldx; a.part = F->d_part;
+  hipLaunchKernelGGL(gbdt_predict_kernel, dim3((unsigned)((n + 63) / 64), n_chunks), dim3(256), 0, st, a);
+  RIHIP_CHECK_LAUNCH();
+  const double scale = F->average_output ? 1.0 / (double)F->n_trees : 1.0;
+  hipLaunchKernelGGL(gbdt_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, F->d_part, n_chunks, n, scale, out);
+  RIHIP_CHECK_LAUNCH();
+  return RIHIP_OK;
+}

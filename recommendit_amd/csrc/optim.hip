@@ -1,0 +1,306 @@
+// Optimiser-side kernels for gfx950 (HBM-bound streaming / row work):
+//   * global grad-norm (clip_grad_norm_, reference src/training/train_embeddings.py:191) as
+//     deterministic two-stage partial sums -> one device scalar, folded into Adam (no host sync)
+//   * dense Adam with coupled L2 (torch.optim.Adam(weight_decay), train_embeddings.py:160,192)
+//   * row-wise sparse path for tables that cannot take a dense pass per step (10M/100M rows):
+//     sort ids -> segment-reduce per unique row (bitwise reproducible, no float atomics)
+//     -> fused row Adam on touched rows only (deviation from the reference stated in DESIGN.md).
+#include "common.h"
+#include "recommendit_hip.h"
+
+#include <cstring>
+#include <string.h>
+#include <rocprim/rocprim.hpp>
+
+namespace {
+
+constexpr int NPART = 64;  // partial sums written per rihip_sumsq call
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t n, double* part) {
+  double acc = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t n4 = n / 4;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const f32x4 v = x4[i];
+    acc += (double)(v.x * v.x + v.y * v.y) + (double)(v.z * v.z + v.w * v.w);
+  }
+  if (blockIdx.x == 0) {
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 256) acc += (double)x[i] * (double)x[i];
+  }
+  acc = wave_sum_d(acc);
+  __shared__ double sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// coef = min(1, max_norm / (sqrt(sum part) + 1e-6))  (torch clip_grad_norm_ semantics)
+__global__ void clip_coef_kernel(const double* __restrict__ part, int n, float max_norm, float* coef, float* norm) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) s += part[i];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) {
+    const float tn = (float)sqrt(s);
+    const float c = max_norm / (tn + 1e-6f);
+    *coef = c < 1.f ? c : 1.f;
+    if (norm) *norm = tn;
+  }
+}
+
+struct AdamHyper {
+  float lr_over_bc1;   // lr / (1 - b1^t)
+  float sqrt_bc2;      // sqrt(1 - b2^t)
+  float b1, b2, eps, wd;
+};
+
+__device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, float coef, const AdamHyper& h) {
+  g = g * coef;
+  if (h.wd != 0.f) g = g + h.wd * p;
+  m = h.b1 * m + (1.f - h.b1) * g;
+  v = h.b2 * v + (1.f - h.b2) * g * g;
+  const float denom = sqrtf(v) / h.sqrt_bc2 + h.eps;
+  p = p - h.lr_over_bc1 * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void adam_dense_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                         const float* coef_dev, AdamHyper h) {
+  const float coef = coef_dev ? *coef_dev : 1.f;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t n4 = n / 4;
+  f32x4* p4 = reinterpret_cast<f32x4*>(p);
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+  f32x4* m4 = reinterpret_cast<f32x4*>(m);
+  f32x4* v4 = reinterpret_cast<f32x4*>(v);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    f32x4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float pk = pp[k], mk = mm[k], vk = vv[k];
+      adam_elem(pk, gg[k], mk, vk, coef, h);
+      pp[k] = pk; mm[k] = mk; vv[k] = vk;
+    }
+    p4[i] = pp; m4[i] = mm; v4[i] = vv;
+  }
+  if (blockIdx.x == 0) {
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 256) adam_elem(p[i], g[i], m[i], v[i], coef, h);
+  }
+}
+
+// ---------------------------------- row-sparse path ---------------------------------------
+__global__ void iota_kernel(int* v, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = (int)i;
+}
+__global__ void head_flags_kernel(const int64_t* __restrict__ sorted, int64_t n, int* flags) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flags[i] = (i == 0 || sorted[i] != sorted[i - 1]) ? 1 : 0;
+}
+// seg[i] = inclusive scan of head flags (1-based segment number); write segment starts + unique ids
+__global__ void seg_starts_kernel(const int64_t* __restrict__ sorted, const int* __restrict__ seg, int64_t n,
+                                  int* seg_start, int64_t* uniq, int* n_unique) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int s = seg[i] - 1;
+  if (i == 0 || seg[i] != seg[i - 1]) {
+    seg_start[s] = (int)i;
+    uniq[s] = sorted[i];
+  }
+  if (i == n - 1) {
+    seg_start[s + 1] = (int)n;
+    *n_unique = s + 1;
+  }
+}
+
+// one wave per unique row: Gc[u] = sum_{k in segment u} dX[perm[k]]   (sorted order => deterministic)
+__global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restrict__ dX, const int* __restrict__ perm,
+                                                          const int* __restrict__ seg_start,
+                                                          const int64_t* __restrict__ uniq,
+                                                          const int* __restrict__ n_unique, int d, float* Gc,
+                                                          double* part) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nu = *n_unique;
+  double acc = 0.0;
+  for (int u = blockIdx.x * 4 + w; u < nu; u += gridDim.x * 4) {
+    const int s0 = seg_start[u], s1 = seg_start[u + 1];
+    const bool pad = uniq[u] == 0;  // padding_idx row: gradient forced to zero (nn.Embedding semantics)
+    for (int c = lane; c < d; c += 64) {
+      float s = 0.f;
+      for (int k = s0; k < s1; ++k) s += dX[(size_t)perm[k] * d + c];
+      if (pad) s = 0.f;
+      Gc[(size_t)u * d + c] = s;
+      acc += (double)s * (double)s;
+    }
+  }
+  acc = wave_sum_d(acc);
+  __shared__ double sh[4];
+  if (lane == 0) sh[w] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ table, float* __restrict__ m,
+                                                        float* __restrict__ v, const int64_t* __restrict__ uniq,
+                                                        const float* __restrict__ Gc,
+                                                        const int* __restrict__ n_unique, int d,
+                                                        const float* coef_dev, AdamHyper h) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nu = *n_unique;
+  const float coef = coef_dev ? *coef_dev : 1.f;
+  for (int u = blockIdx.x * 4 + w; u < nu; u += gridDim.x * 4) {
+    const size_t row = (size_t)uniq[u] * d;
+    for (int c = lane; c < d; c += 64) {
+      float p = table[row + c], mm = m[row + c], vv = v[row + c];
+      adam_elem(p, Gc[(size_t)u * d + c], mm, vv, coef, h);
+      table[row + c] = p; m[row + c] = mm; v[row + c] = vv;
+    }
+  }
+}
+
+AdamHyper make_hyper(float lr, float b1, float b2, float eps, float wd, int64_t step) {
+  AdamHyper h;
+  const double bc1 = 1.0 - pow((double)b1, (double)step);
+  const double bc2 = 1.0 - pow((double)b2, (double)step);
+  h.lr_over_bc1 = (float)((double)lr / bc1);
+  h.sqrt_bc2 = (float)sqrt(bc2);
+  h.b1 = b1; h.b2 = b2; h.eps = eps; h.wd = wd;
+  return h;
+}
+
+constexpr int ROWS_GRID = 1024;
+
+}  // namespace
+
+extern "C" int rihip_sumsq_nparts(void) { return NPART; }
+extern "C" int rihip_rows_nparts(void) { return ROWS_GRID; }
+
+extern "C" int rihip_sumsq(const float* x, int64_t n, double* part, void* stream) {
+  RIHIP_REQUIRE(x && part && n >= 0, RIHIP_ERR_ARG, "sumsq: bad arguments");
+  RIHIP_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, RIHIP_ERR_ARG, "sumsq: x must be 16-byte aligned");
+  hipLaunchKernelGGL(sumsq_kernel, dim3(NPART), dim3(256), 0, (hipStream_t)stream, x, n, part);
+  RIHIP_CHECK_LAUNCH();
+  return RIHIP_OK;
+}
+
+extern "C" int rihip_clip_coef(const double* part, int64_t n_part, float max_norm, float* coef, float* total_norm,
+                               void* stream) {
+  RIHIP_REQUIRE(part && coef && n_part > 0, RIHIP_ERR_ARG, "clip_coef: bad arguments");
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, part, (int)n_part, max_norm, coef,
+                     total_norm);
+  RIHIP_CHECK_LAUNCH();
+  return RIHIP_OK;
+}
+
+extern "C" int rihip_adam_dense(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                                float beta2, float eps, float weight_decay, int64_t step, const float* clip_coef,
+                                void* stream) {
+  RIHIP_REQUIRE(p && g && m && v && n >= 0 && step >= 1, RIHIP_ERR_ARG, "adam_dense: bad arguments");
+  RIHIP_REQUIRE(((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                  reinterpret_cast<uintptr_t>(v)) & 15) == 0,
+                RIHIP_ERR_ARG, "adam_dense: pointers must be 16-byte aligned");
+  if (n == 0) return RIHIP_OK;
+  const int64_t nb = (n / 4 + 255) / 256;
+  const int grid = (int)(nb < 1 ? 1 : (nb < 2048 ? nb : 2048));
+  hipLaunchKernelGGL(adam_dense_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, clip_coef,
+                     make_hyper(lr, beta1, beta2, eps, weight_decay, step));
+  RIHIP_CHECK_LAUNCH();
+  return RIHIP_OK;
+}
+
+// ---- row-sparse path ------------------------------------------------------------------------
+// workspace layout (bytes), all 256-B aligned:
+//   keys_out int64[B] | vals_in int32[B] | perm int32[B] | flags int32[B] | seg int32[B] |
+//   seg_start int32[B+1] | n_unique int32 | rocprim temp
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct RowsWs {
+  int64_t* keys_out; int* vals_in; int* perm; int* flags; int* seg; int* seg_start; int* n_unique; void* temp;
+  size_t temp_bytes; size_t total;
+};
+
+static int rows_ws_layout(int64_t B, void* base, RowsWs* ws) {
+  size_t sort_bytes = 0, scan_bytes = 0;
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, sort_bytes, (const int64_t*)nullptr, (int64_t*)nullptr,
+                                           (const int*)nullptr, (int*)nullptr, (size_t)B);
+  if (e != hipSuccess) return RIHIP_ERR_HIP;
+  e = rocprim::inclusive_scan(nullptr, scan_bytes, (const int*)nullptr, (int*)nullptr, (size_t)B, rocprim::plus<int>());
+  if (e != hipSuccess) return RIHIP_ERR_HIP;
+  size_t off = 0;
+  char* b = (char*)base;
+  ws->keys_out = (int64_t*)(b + off); off += align256(sizeof(int64_t) * B);
+  ws->vals_in = (int*)(b + off); off += align256(sizeof(int) * B);
+  ws->perm = (int*)(b + off); off += align256(sizeof(int) * B);
+  ws->flags = (int*)(b + off); off += align256(sizeof(int) * B);
+  ws->seg = (int*)(b + off); off += align256(sizeof(int) * B);
+  ws->seg_start = (int*)(b + off); off += align256(sizeof(int) * (B + 1));
+  ws->n_unique = (int*)(b + off); off += 256;
+  ws->temp = (void*)(b + off);
+  ws->temp_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
+  off += align256(ws->temp_bytes);
+  ws->total = off;
+  return RIHIP_OK;
+}
+
+extern "C" int64_t rihip_rows_workspace_bytes(int64_t B) {
+  RowsWs ws;
+  if (B <= 0 || rows_ws_layout(B, nullptr, &ws) != RIHIP_OK) return -1;
+  return (int64_t)ws.total;
+}
+
+// Groups the B (id, sample) pairs by id.  Outputs (device): uniq[<=B] unique ids ascending,
+// and inside the workspace perm / seg_start / n_unique used by rihip_rows_reduce / rihip_adam_rows.
+extern "C" int rihip_rows_group(const int64_t* ids, int64_t B, int64_t* uniq, void* workspace, int64_t workspace_bytes,
+                                void* stream) {
+  RIHIP_REQUIRE(ids && uniq && workspace && B > 0 && B < (1ll << 31), RIHIP_ERR_ARG, "rows_group: bad arguments");
+  RowsWs ws;
+  RIHIP_REQUIRE(rows_ws_layout(B, workspace, &ws) == RIHIP_OK, RIHIP_ERR_HIP, "rows_group: rocprim size query failed");
+  RIHIP_REQUIRE((int64_t)ws.total <= workspace_bytes, RIHIP_ERR_ARG, "rows_group: workspace too small (%zu > %lld)",
+                ws.total, (long long)workspace_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned nb = (unsigned)((B + 255) / 256);
+  hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(256), 0, st, ws.vals_in, B);
+  RIHIP_CHECK_LAUNCH();
+  size_t tb = ws.temp_bytes;
+  RIHIP_CHECK_HIP(rocprim::radix_sort_pairs(ws.temp, tb, ids, ws.keys_out, ws.vals_in, ws.perm, (size_t)B, 0, 64, st));
+  hipLaunchKernelGGL(head_flags_kernel, dim3(nb), dim3(256), 0, st, ws.keys_out, B, ws.flags);
+  RIHIP_CHECK_LAUNCH();
+  tb = ws.temp_bytes;
+  RIHIP_CHECK_HIP(rocprim::inclusive_scan(ws.temp, tb, ws.flags, ws.seg, (size_t)B, rocprim::plus<int>(), st));
+  hipLaunchKernelGGL(seg_starts_kernel, dim3(nb), dim3(256), 0, st, ws.keys_out, ws.seg, B, ws.seg_start, uniq,
+                     ws.n_unique);
+  RIHIP_CHECK_LAUNCH();
+  return RIHIP_OK;
+}
+
+extern "C" int rihip_rows_n_unique_ptr(void* workspace, int64_t B, const int** out) {
+  RowsWs ws;
+  RIHIP_REQUIRE(rows_ws_layout(B, workspace, &ws) == RIHIP_OK, RIHIP_ERR_HIP, "rows: size query failed");
+  *out = ws.n_unique;
+  return RIHIP_OK;
+}
+
+// Gc[u] = sum of dX rows of unique row u; part[rihip_rows_nparts()] = partial sums of |Gc|^2
+extern "C" int rihip_rows_reduce(const float* dX, int64_t B, int d, const int64_t* uniq, void* workspace, float* Gc,
+                                 double* part, void* stream) {
+  RIHIP_REQUIRE(dX && uniq && workspace && Gc && part && B > 0, RIHIP_ERR_ARG, "rows_reduce: bad arguments");
+  RowsWs ws;
+  RIHIP_REQUIRE(rows_ws_layout(B, workspace, &ws) == RIHIP_OK, RIHIP_ERR_HIP, "rows_reduce: size query failed");
+  hipLaunchKernelGGL(rows_reduce_kernel, dim3(ROWS_GRID), dim3(256), 0, (hipStream_t)stream, dX, ws.perm, ws.seg_start,
+                     uniq, ws.n_unique, d, Gc, part);
+  RIHIP_CHECK_LAUNCH();
+  return RIHIP_OK;
+}
+
+extern "C" int rihip_adam_rows(float* table, float* m, float* v, const int64_t* uniq, const float* Gc, int64_t B,
+                               int d, void* workspace, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, int64_t step, const float* clip_coef, void* stream) {
+  RIHIP_REQUIRE(table && m && v && uniq && Gc && workspace && B > 0 && step >= 1, RIHIP_ERR_ARG,
+                "adam_rows: bad arguments");
+  RowsWs ws;
+  RIHIP_REQUIRE(rows_ws_layout(B, workspace, &ws) == RIHIP_OK, RIHIP_ERR_HIP, "adam_rows: size query failed");
+  hipLaunchKernelGGL(adam_rows_kernel, dim3(ROWS_GRID), dim3(256), 0, (hipStream_t)stream, table, m, v, uniq, Gc,
+                     ws.n_unique, d, clip_coef, make_hyper(lr, beta1, beta2, eps, weight_decay, step));
+  RIHIP_CHECK_LAUNCH();
+  return RIHIP_OK;
+}

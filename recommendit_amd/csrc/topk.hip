@@ -1,0 +1,814 @@
+// Inner-product top-K retrieval for gfx950 -- replaces the faiss calls behind
+// FAISSIndex.search / batch_search (reference src/models/faiss_index.py:113, :145).
+//
+// Exact brute force, three launches per query batch, no score matrix in HBM:
+//   (0) threshold estimate: score a strided sample of the corpus, radix-select the r-th
+//       largest sample score per query  (r chosen so that P(#{score>=thr} < k) ~ 1e-5)
+//   (1) scan: 4 waves x 32 register-stationary queries per workgroup; corpus tiles stream
+//       through LDS once per 128 queries; S tile on exact-f32 MFMA; scores >= thr[q] are
+//       appended (score,row) to the query's candidate list (rare: ~0.1-0.3 % of scores)
+//   (2) finalize: one workgroup per query radix-selects the k best 64-bit keys
+//       (orderable score << 32 | ~row: ties -> lowest row, total order) and bitonic-sorts them.
+//   Queries whose candidate list under- or overflows (heavy ties / adversarial data) are
+//   re-done exactly with thr=-inf and capacity N ("fallback"), so the result is always exact.
+//
+// IVF-Flat (IP): k-means lists built on device, corpus re-ordered list-contiguous and padded
+// to the 64-row tile so a tile belongs to one list; the scan skips tiles whose list no query
+// of the block probes and masks per query.
+#include "common.h"
+#include "recommendit_hip.h"
+
+#include <algorithm>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+namespace {
+
+constexpr int TR = 64;          // corpus rows per LDS tile
+constexpr int QB = 128;         // queries per workgroup (32 per wave)
+constexpr int K_MAX = 2048;     // largest k served by the device sort buffer
+constexpr int SAMPLE = 16384;   // corpus rows scored for the threshold estimate
+
+__device__ __forceinline__ uint32_t f2ord(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o) {
+  uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+  return __uint_as_float(u);
+}
+__device__ __forceinline__ uint64_t make_key(float s, uint32_t row) {
+  return ((uint64_t)f2ord(s) << 32) | (uint64_t)(0xFFFFFFFFu - row);
+}
+
+struct ScanArgs {
+  const float* X;        // corpus [N,d] (list-ordered for IVF)
+  int64_t n_virtual;     // virtual rows scanned: row(i) = i * row_stride
+  int64_t row_stride;
+  const float* Q;        // [nq,d]
+  int64_t nq;
+  const float* thr;      // [nq] or null (=> -inf)
+  uint64_t* cand;        // [nq, cap]
+  int64_t cap;
+  int* count;            // [nq]
+  int nsplit;            // corpus splits (gridDim.y)
+  int dense;             // 1: slot = virtual row (no atomics, count preset); 0: atomic append
+  // IVF (all null/0 for brute force)
+  const int* tile_list;       // [n_tiles] list id of each 64-row tile
+  const uint32_t* probe_bits; // [nq, pb_words] bitset of probed lists
+  int pb_words;
+  const int64_t* row_ids;     // [N] original row id per physical row (IVF), or null
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void scan_kernel(ScanArgs a) {
+  constexpr int LDX = D + 4, KB = D / 8;
+  __shared__ __attribute__((aligned(16))) float Xs[TR * LDX];
+  __shared__ int any_probe;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r31 = lane & 31, hh = lane >> 5;
+  const int64_t q = (int64_t)blockIdx.x * QB + w * 32 + r31;
+  const bool q_ok = q < a.nq;
+  const int64_t qrow = q_ok ? q : (a.nq - 1);
+
+  f32x4 qf[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) qf[kb] = *reinterpret_cast<const f32x4*>(&a.Q[qrow * D + kb * 8 + 4 * hh]);
+  const float thr = (a.thr && q_ok) ? a.thr[q] : -INFINITY;
+  uint64_t* my_cand = a.cand + (size_t)qrow * a.cap;
+
+  const int64_t n_tiles = (a.n_virtual + TR - 1) / TR;
+  const int64_t t_per = (n_tiles + a.nsplit - 1) / a.nsplit;
+  const int64_t t0 = (int64_t)blockIdx.y * t_per;
+  const int64_t t1 = (t0 + t_per < n_tiles) ? t0 + t_per : n_tiles;
+
+  for (int64_t tile = t0; tile < t1; ++tile) {
+    const int64_t v_base = tile * TR;
+    bool probes = true;
+    if (a.tile_list) {  // IVF: does anyone in this block probe the tile's list?
+      const int L = a.tile_list[tile];
+      probes = q_ok && ((a.probe_bits[(size_t)q * a.pb_words + (L >> 5)] >> (L & 31)) & 1u);
+      if (tid == 0) any_probe = 0;
+      __syncthreads();
+      if (probes) any_probe = 1;
+      __syncthreads();
+      if (!any_probe) continue;  // uniform across the workgroup
+    }
+    for (int idx = tid; idx < TR * (D / 4); idx += 256) {
+      const int r = idx / (D / 4), c4 = idx % (D / 4);
+      const int64_t v = v_base + r;
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      if (v < a.n_virtual) val = reinterpret_cast<const f32x4*>(a.X + (size_t)(v * a.row_stride) * D)[c4];
+      *reinterpret_cast<f32x4*>(&Xs[r * LDX + c4 * 4]) = val;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rt = 0; rt < TR / 32; ++rt) {
+      f32x16 acc = zero16();
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(&Xs[(rt * 32 + r31) * LDX + kb * 8 + 4 * hh]);
+        acc = mfma32(av.x, qf[kb].x, acc);
+        acc = mfma32(av.y, qf[kb].y, acc);
+        acc = mfma32(av.z, qf[kb].z, acc);
+        acc = mfma32(av.w, qf[kb].w, acc);
+      }
+      if (q_ok && a.dense) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t v = v_base + rt * 32 + acc_row(r, lane);
+          if (v < a.n_virtual) my_cand[v] = make_key(acc[r], (uint32_t)v);
+        }
+      } else if (q_ok && probes) {
+        // per-lane aggregation: one atomic per (query, 32-row tile) that has hits
+        unsigned hits = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t v = v_base + rt * 32 + acc_row(r, lane);
+          if (v < a.n_virtual && acc[r] >= thr) hits |= (1u << r);
+        }
+        if (hits) {
+          int pos = atomicAdd(&a.count[q], __popc(hits));
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (hits & (1u << r)) {
+              const int64_t v = v_base + rt * 32 + acc_row(r, lane);
+              const int64_t rid = a.row_ids ? a.row_ids[v] : v;
+              // padding rows (rid<0) keep their slot with the lowest key so counts stay consistent
+              if (pos < a.cap) my_cand[pos] = (rid >= 0) ? make_key(acc[r], (uint32_t)rid) : 0ull;
+              ++pos;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- finalize: radix-select the k_sel best keys of query q, sort them, emit -------------------
+struct FinArgs {
+  const uint64_t* cand;  // [nq, cap]
+  int64_t cap;
+  const int* count;      // [nq]
+  const int* qmap;       // optional: output slot -> query index inside cand/count (fallback), or null
+  int64_t nq;
+  int k;                 // requested k (<= K_MAX)
+  // mode 0: write top-k scores/rows ; mode 1: write thr[q] = score of the k_sel-th key
+  int mode;
+  int rank;              // mode 1: r
+  float* out_scores;     // [nq_out, k]
+  int64_t* out_rows;     // [nq_out, k]
+  const int* out_slot;   // optional: where query i's results go (fallback), or null
+  float* thr_out;        // mode 1
+  int* fail_flags;       // [nq] mode 0: 1 if count<need_min or count>cap
+  int64_t need_min;      // min(k, N_effective): candidates required for exactness (0 => no check)
+};
+
+__global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
+  __shared__ unsigned hist[256];
+  __shared__ uint64_t sbuf[K_MAX];
+  __shared__ unsigned s_bin, s_above, s_cnt;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int64_t qi = blockIdx.x;
+  const int64_t q = a.qmap ? a.qmap[qi] : qi;
+  const int cnt_raw = a.count[q];
+  const int64_t n = cnt_raw < a.cap ? cnt_raw : a.cap;
+  const uint64_t* keys = a.cand + (size_t)q * a.cap;
+  const int64_t oslot = a.out_slot ? a.out_slot[qi] : qi;
+
+  if (a.mode == 0 && a.fail_flags) {
+    const bool fail = (cnt_raw > a.cap) || (a.need_min > 0 && cnt_raw < a.need_min);
+    if (tid == 0) a.fail_flags[q] = fail ? 1 : 0;
+  }
+  int k_sel = (a.mode == 0) ? a.k : a.rank;
+  if (k_sel > n) k_sel = (int)n;
+
+  uint64_t T = 0;  // k_sel-th largest key
+  if (k_sel > 0) {
+    uint64_t prefix = 0, mask = 0;
+    unsigned need = (unsigned)k_sel;
+    for (int pass = 0; pass < 8; ++pass) {
+      const int shift = 56 - 8 * pass;
+      hist[tid] = 0;
+      __syncthreads();
+      for (int64_t i = tid; i < n; i += 256) {
+        const uint64_t key = keys[i];
+        if ((key & mask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (tid < 64) {  // wave 0: suffix scan over bins 255..0, 4 bins per lane
+        const int b0 = 255 - 4 * lane;
+        const unsigned h0 = hist[b0], h1 = hist[b0 - 1], h2 = hist[b0 - 2], h3 = hist[b0 - 3];
+        const unsigned mine = h0 + h1 + h2 + h3;
+        unsigned incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const unsigned t = __shfl_up(incl, o, 64);
+          if (lane >= o) incl += t;
+        }
+        const unsigned before = incl - mine;
+        if (before < need && need <= incl) {
+          unsigned c = before;
+          int b = b0;
+          if (c + h0 >= need) { b = b0; }
+          else { c += h0; if (c + h1 >= need) { b = b0 - 1; }
+          else { c += h1; if (c + h2 >= need) { b = b0 - 2; }
+          else { c += h2; b = b0 - 3; } } }
+          s_bin = (unsigned)b;
+          s_above = c;
+        }
+      }
+      __syncthreads();
+      need -= s_above;
+      prefix |= (uint64_t)s_bin << shift;
+      mask |= 0xFFull << shift;
+      __syncthreads();
+    }
+    T = prefix;
+  }
+
+  if (a.mode == 1) {
+    if (tid == 0) a.thr_out[q] = (k_sel > 0) ? ord2f((uint32_t)(T >> 32)) : -INFINITY;
+    return;
+  }
+
+  // compact keys >= T (exactly k_sel of them: keys are unique), pad to pow2, bitonic sort descending
+  int P = 64;
+  while (P < k_sel) P <<= 1;
+  if (tid == 0) s_cnt = 0;
+  for (int i = tid; i < P; i += 256) sbuf[i] = 0ull;
+  __syncthreads();
+  if (k_sel > 0) {
+    for (int64_t i = tid; i < n; i += 256) {
+      const uint64_t key = keys[i];
+      if (key > T) {
+        const unsigned pos = atomicAdd(&s_cnt, 1u);
+        if (pos < (unsigned)K_MAX) sbuf[pos] = key;
+      }
+    }
+  }
+  __syncthreads();
+  {  // keys are unique except the all-zero padding key: the remaining slots all equal T
+    const int cgt = (int)s_cnt;
+    for (int i = cgt + tid; i < k_sel; i += 256) sbuf[i] = T;
+  }
+  __syncthreads();
+  for (int size = 2; size <= P; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = tid; i < P / 2; i += 256) {
+        const int lo = (i / stride) * (stride << 1) + (i % stride);
+        const int hi = lo + stride;
+        const bool desc = ((lo & size) == 0);
+        const uint64_t x = sbuf[lo], y = sbuf[hi];
+        if (desc ? (x < y) : (x > y)) { sbuf[lo] = y; sbuf[hi] = x; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < a.k; i += 256) {
+    float sc = -INFINITY;
+    int64_t row = -1;
+    if (i < k_sel && sbuf[i] != 0ull) {
+      const uint64_t key = sbuf[i];
+      sc = ord2f((uint32_t)(key >> 32));
+      row = (int64_t)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull));
+    }
+    a.out_scores[oslot * a.k + i] = sc;
+    a.out_rows[oslot * a.k + i] = row;
+  }
+}
+
+__global__ void collect_fail_kernel(const int* __restrict__ flags, int64_t nq, int* list, int* n_fail) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nq && flags[i]) list[atomicAdd(n_fail, 1)] = (int)i;
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ Q, const int* __restrict__ idx, int n, int d, float* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (int64_t)n * d) out[i] = Q[(size_t)idx[i / d] * d + (i % d)];
+}
+
+__global__ void map_rows_kernel(int64_t* rows, int64_t n, const int64_t* __restrict__ ids) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const int64_t r = rows[i]; rows[i] = (r >= 0) ? ids[r] : -1; }
+}
+
+// ---------------------------------------- IVF build --------------------------------------------
+// assignment by max inner product with the centroid (IndexFlatIP quantizer); one wave per row
+__global__ __launch_bounds__(256) void ivf_assign_kernel(const float* __restrict__ X, int64_t N, int d,
+                                                         const float* __restrict__ C, int nlist, int* assign) {
+  extern __shared__ float Cs[];  // [nlist*d]
+  for (int i = threadIdx.x; i < nlist * d; i += 256) Cs[i] = C[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < N; row += (int64_t)gridDim.x * 4) {
+    float best = -INFINITY;
+    int bi = 0;
+    for (int c = 0; c < nlist; ++c) {
+      float s = 0.f;
+      for (int k = lane; k < d; k += 64) s += X[row * d + k] * Cs[c * d + k];
+      s = wave_sum(s);
+      if (s > best) { best = s; bi = c; }
+    }
+    if (lane == 0) assign[row] = bi;
+  }
+}
+
+// per-workgroup LDS accumulation of centroid sums, then one slab per workgroup (deterministic reduce)
+__global__ __launch_bounds__(256) void ivf_accum_kernel(const float* __restrict__ X, int64_t N, int d,
+                                                        const int* __restrict__ assign, int nlist, float* slab,
+                                                        int* cnt_slab) {
+  extern __shared__ float Ss[];  // [nlist*d] sums | [nlist] counts (as float bits of int)
+  int* Cn = reinterpret_cast<int*>(Ss + (size_t)nlist * d);
+  for (int i = threadIdx.x; i < nlist * d; i += 256) Ss[i] = 0.f;
+  for (int i = threadIdx.x; i < nlist; i += 256) Cn[i] = 0;
+  __syncthreads();
+  const int64_t per = (N + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * per, r1 = (r0 + per < N) ? r0 + per : N;
+  // rows processed in order by the whole block: thread t adds column t (and t+256...) => deterministic
+  for (int64_t row = r0; row < r1; ++row) {
+    const int c = assign[row];
+    for (int k = threadIdx.x; k < d; k += 256) Ss[c * d + k] += X[row * d + k];
+    if (threadIdx.x == 0) Cn[c] += 1;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nlist * d; i += 256) slab[(size_t)blockIdx.x * nlist * d + i] = Ss[i];
+  for (int i = threadIdx.x; i < nlist; i += 256) cnt_slab[(size_t)blockIdx.x * nlist + i] = Cn[i];
+}
+
+__global__ void ivf_update_kernel(const float* __restrict__ slab, const int* __restrict__ cnt_slab, int nslab, int nlist,
+                                  int d, float* C, int* counts, int update_c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nlist * d) return;
+  const int c = i / d;
+  float s = 0.f;
+  int n = 0;
+  for (int k = 0; k < nslab; ++k) { s += slab[(size_t)k * nlist * d + i]; n += cnt_slab[(size_t)k * nlist + c]; }
+  if (update_c && n > 0) C[i] = s / (float)n;  // empty list keeps its previous centroid
+  if ((i % d) == 0) counts[c] = n;
+}
+
+// coarse quantizer: top-nprobe lists per query by IP -> probe bitset (one wave per query)
+__global__ __launch_bounds__(256) void ivf_probe_kernel(const float* __restrict__ Q, int64_t nq, int d,
+                                                        const float* __restrict__ C, int nlist, int nprobe,
+                                                        uint32_t* bits, int pb_words) {
+  extern __shared__ float sc[];  // [4][nlist]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t q = (int64_t)blockIdx.x * 4 + w;
+  if (q >= nq) return;
+  float* my = sc + (size_t)w * nlist;
+  for (int c = 0; c < nlist; ++c) {
+    float s = 0.f;
+    for (int k = lane; k < d; k += 64) s += Q[q * d + k] * C[c * d + k];
+    s = wave_sum(s);
+    if (lane == 0) my[c] = s;
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < pb_words; i += 64) bits[(size_t)q * pb_words + i] = 0u;
+  __builtin_amdgcn_wave_barrier();
+  // nprobe rounds of argmax (ties -> lowest list id)
+  for (int p = 0; p < nprobe && p < nlist; ++p) {
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < nlist; c += 64) {
+      const float v = my[c];
+      if (v > best || (v == best && c < bi)) { best = v; bi = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0 && bi != 0x7fffffff) {
+      bits[(size_t)q * pb_words + (bi >> 5)] |= (1u << (bi & 31));
+      my[bi] = -INFINITY;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+__global__ void zero_int_kernel(int* p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0;
+}
+
+// ------------------------------------------ handle ---------------------------------------------
+__global__ void fill_int_kernel(int* p, int64_t n, int v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  int64_t n = 0;
+  int reserve(int64_t want) {
+    if (n >= want) return RIHIP_OK;
+    if (p) hipFree(p);
+    p = nullptr; n = 0;
+    if (hipMalloc((void**)&p, sizeof(T) * (size_t)want) != hipSuccess) {
+      rihip_set_error("ip_index: device allocation of %lld bytes failed", (long long)(sizeof(T) * (size_t)want));
+      return RIHIP_ERR_HIP;
+    }
+    n = want;
+    return RIHIP_OK;
+  }
+  void release() { if (p) hipFree(p); p = nullptr; n = 0; }
+};
+
+struct IpIndex {
+  int d = 0;
+  int64_t N = 0;         // real vectors
+  float* X = nullptr;    // brute force: [N,d]; IVF: [Np,d] list-ordered, zero-padded to 64-row tiles
+  // IVF
+  int nlist = 0, nprobe = 1;
+  bool ivf = false;
+  int64_t Np = 0;              // padded physical rows
+  float* C = nullptr;          // [nlist,d]
+  int* tile_list = nullptr;    // [Np/64]
+  int64_t* row_ids = nullptr;  // [Np] original row per physical row, -1 for padding
+  std::vector<int64_t> list_len;  // host copy
+  // scratch (grown on demand, owned by the handle)
+  DevBuf<uint64_t> cand, scand, fcand;
+  DevBuf<int> count, fail_flags, fail_list, n_fail, fcount;
+  DevBuf<float> thr, fQ;
+  DevBuf<uint32_t> probe_bits;
+  int* h_nfail = nullptr;  // pinned
+};
+
+#define HIPCHK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { rihip_set_error("%s:%d %s", __FILE__, __LINE__, hipGetErrorString(_e)); return RIHIP_ERR_HIP; } } while (0)
+#define RCCHK(e) do { int _rc = (e); if (_rc) return _rc; } while (0)
+
+void free_index_arrays(IpIndex* h) {
+  hipFree(h->X); hipFree(h->C); hipFree(h->tile_list); hipFree(h->row_ids);
+  h->X = nullptr; h->C = nullptr; h->tile_list = nullptr; h->row_ids = nullptr;
+  h->N = 0; h->Np = 0; h->ivf = false; h->list_len.clear();
+}
+
+template <int D>
+void launch_scan(const ScanArgs& a, dim3 grid, hipStream_t st) {
+  hipLaunchKernelGGL((scan_kernel<D>), grid, dim3(256), 0, st, a);
+}
+int dispatch_scan(int d, const ScanArgs& a, dim3 grid, hipStream_t st) {
+  if (d == 32) launch_scan<32>(a, grid, st);
+  else if (d == 64) launch_scan<64>(a, grid, st);
+  else if (d == 128) launch_scan<128>(a, grid, st);
+  else { rihip_set_error("ip_index: unsupported embed_dim=%d (32/64/128)", d); return RIHIP_ERR_SHAPE; }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { rihip_set_error("scan launch: %s", hipGetErrorString(e)); return RIHIP_ERR_HIP; }
+  return RIHIP_OK;
+}
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { rihip_set_error("%s launch: %s", what, hipGetErrorString(e)); return RIHIP_ERR_HIP; }
+  return RIHIP_OK;
+}
+
+int pick_nsplit(int64_t nq, int64_t n_tiles) {
+  const int64_t qblocks = (nq + QB - 1) / QB;
+  int64_t ns = (2 * RIHIP_NCU + qblocks - 1) / qblocks;  // aim at >= 2 workgroups per CU
+  if (ns > n_tiles) ns = n_tiles;
+  if (ns < 1) ns = 1;
+  if (ns > 65535) ns = 65535;
+  return (int)ns;
+}
+
+int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, int64_t* out_r, hipStream_t st) {
+  const int d = h->d;
+  const int64_t Nphys = h->ivf ? h->Np : h->N;
+  const int64_t n_tiles = (Nphys + TR - 1) / TR;
+  const unsigned nqb = (unsigned)((nq + 255) / 256);
+  const unsigned qgrid = (unsigned)((nq + QB - 1) / QB);
+  RCCHK(h->count.reserve(nq));
+  RCCHK(h->fail_flags.reserve(nq));
+  RCCHK(h->fail_list.reserve(nq));
+  RCCHK(h->thr.reserve(nq));
+  RCCHK(h->n_fail.reserve(1));
+  if (!h->h_nfail) HIPCHK(hipHostMalloc((void**)&h->h_nfail, sizeof(int)));
+
+  ScanArgs sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.X = h->X; sa.Q = Q; sa.nq = nq; sa.count = h->count.p;
+  FinArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  fa.nq = nq; fa.k = k; fa.count = h->count.p; fa.out_scores = out_s; fa.out_rows = out_r;
+
+  if (h->ivf) {
+    // candidates = every vector of the probed lists; upper bound = the nprobe longest lists (padded)
+    std::vector<int64_t> ll = h->list_len;
+    std::sort(ll.begin(), ll.end(), [](int64_t x, int64_t y) { return x > y; });
+    int64_t cap = 0;
+    for (int i = 0; i < h->nprobe && i < (int)ll.size(); ++i) cap += (ll[i] + TR - 1) / TR * TR;
+    if (cap < 1) cap = 1;
+    RCCHK(h->cand.reserve(nq * cap));
+    const int pbw = (h->nlist + 31) / 32;
+    RCCHK(h->probe_bits.reserve(nq * pbw));
+    hipLaunchKernelGGL(ivf_probe_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), sizeof(float) * 4 * h->nlist, st, Q,
+                       nq, d, h->C, h->nlist, h->nprobe, h->probe_bits.p, pbw);
+    hipLaunchKernelGGL(fill_int_kernel, dim3(nqb), dim3(256), 0, st, h->count.p, nq, 0);
+    sa.n_virtual = Nphys; sa.row_stride = 1; sa.thr = nullptr; sa.cand = h->cand.p; sa.cap = cap; sa.dense = 0;
+    sa.nsplit = pick_nsplit(nq, n_tiles);
+    sa.tile_list = h->tile_list; sa.probe_bits = h->probe_bits.p; sa.pb_words = pbw; sa.row_ids = h->row_ids;
+    RCCHK(dispatch_scan(d, sa, dim3(qgrid, sa.nsplit), st));
+    fa.cand = h->cand.p; fa.cap = cap; fa.mode = 0;
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3(256), 0, st, fa);
+    return check_launch("finalize");
+  }
+
+  if (h->N <= 4 * (int64_t)SAMPLE) {
+    // small corpus: every score is a candidate (dense slots, no atomics)
+    RCCHK(h->cand.reserve(nq * h->N));
+    hipLaunchKernelGGL(fill_int_kernel, dim3(nqb), dim3(256), 0, st, h->count.p, nq, (int)h->N);
+    sa.n_virtual = h->N; sa.row_stride = 1; sa.thr = nullptr; sa.cand = h->cand.p; sa.cap = h->N; sa.dense = 1;
+    sa.nsplit = pick_nsplit(nq, n_tiles);
+    RCCHK(dispatch_scan(d, sa, dim3(qgrid, sa.nsplit), st));
+    fa.cand = h->cand.p; fa.cap = h->N; fa.mode = 0;
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3(256), 0, st, fa);
+    return check_launch("finalize");
+  }
+
+  // ---- pass 0: threshold from a strided sample
+  const int64_t stride = h->N / SAMPLE;
+  const int64_t S = (h->N + stride - 1) / stride;  // virtual rows i*stride < N
+  const double m = (double)k * (double)S / (double)h->N;
+  const int rank = (int)ceil(m + 4.0 * sqrt(m) + 4.0);
+  const double expect = (double)rank * (double)h->N / (double)S;
+  int64_t cap = 4096;
+  while ((double)cap < 2.5 * expect) cap <<= 1;
+  if (cap > h->N) cap = h->N;
+  RCCHK(h->scand.reserve(nq * S));
+  RCCHK(h->cand.reserve(nq * cap));
+  hipLaunchKernelGGL(fill_int_kernel, dim3(nqb), dim3(256), 0, st, h->count.p, nq, (int)S);
+  sa.n_virtual = S; sa.row_stride = stride; sa.thr = nullptr; sa.cand = h->scand.p; sa.cap = S; sa.dense = 1;
+  sa.nsplit = pick_nsplit(nq, (S + TR - 1) / TR);
+  RCCHK(dispatch_scan(d, sa, dim3(qgrid, sa.nsplit), st));
+  fa.cand = h->scand.p; fa.cap = S; fa.mode = 1; fa.rank = rank; fa.thr_out = h->thr.p;
+  hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3(256), 0, st, fa);
+  // ---- pass 1: thresholded scan (atomic append of the rare survivors)
+  hipLaunchKernelGGL(fill_int_kernel, dim3(nqb), dim3(256), 0, st, h->count.p, nq, 0);
+  sa.n_virtual = h->N; sa.row_stride = 1; sa.thr = h->thr.p; sa.cand = h->cand.p; sa.cap = cap; sa.dense = 0;
+  sa.nsplit = pick_nsplit(nq, n_tiles);
+  RCCHK(dispatch_scan(d, sa, dim3(qgrid, sa.nsplit), st));
+  // ---- pass 2: finalize + exactness flags
+  fa.cand = h->cand.p; fa.cap = cap; fa.mode = 0; fa.fail_flags = h->fail_flags.p;
+  fa.need_min = k < h->N ? k : h->N; fa.thr_out = nullptr;
+  hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3(256), 0, st, fa);
+  hipLaunchKernelGGL(fill_int_kernel, dim3(1), dim3(64), 0, st, h->n_fail.p, 1, 0);
+  hipLaunchKernelGGL(collect_fail_kernel, dim3(nqb), dim3(256), 0, st, h->fail_flags.p, nq, h->fail_list.p, h->n_fail.p);
+  RCCHK(check_launch("finalize"));
+  HIPCHK(hipMemcpyAsync(h->h_nfail, h->n_fail.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  const int nf = *h->h_nfail;
+  if (nf > 0) {  // exact re-do of under/overflowed queries (heavy ties, adversarial data)
+    const int FCH = 8;
+    RCCHK(h->fcand.reserve((int64_t)FCH * h->N));
+    RCCHK(h->fQ.reserve((int64_t)FCH * d));
+    RCCHK(h->fcount.reserve(FCH));
+    for (int f0 = 0; f0 < nf; f0 += FCH) {
+      const int nfc = (nf - f0 < FCH) ? nf - f0 : FCH;
+      hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((nfc * d + 255) / 256)), dim3(256), 0, st, Q,
+                         h->fail_list.p + f0, nfc, d, h->fQ.p);
+      hipLaunchKernelGGL(fill_int_kernel, dim3(1), dim3(64), 0, st, h->fcount.p, nfc, (int)h->N);
+      ScanArgs fs;
+      memset(&fs, 0, sizeof(fs));
+      fs.X = h->X; fs.n_virtual = h->N; fs.row_stride = 1; fs.Q = h->fQ.p; fs.nq = nfc; fs.thr = nullptr;
+      fs.cand = h->fcand.p; fs.cap = h->N; fs.count = h->fcount.p; fs.dense = 1; fs.nsplit = pick_nsplit(nfc, n_tiles);
+      RCCHK(dispatch_scan(d, fs, dim3(1, fs.nsplit), st));
+      FinArgs ff;
+      memset(&ff, 0, sizeof(ff));
+      ff.cand = h->fcand.p; ff.cap = h->N; ff.count = h->fcount.p; ff.nq = nfc; ff.k = k; ff.mode = 0;
+      ff.out_scores = out_s; ff.out_rows = out_r; ff.out_slot = h->fail_list.p + f0;
+      hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nfc), dim3(256), 0, st, ff);
+    }
+    RCCHK(check_launch("fallback"));
+  }
+  return RIHIP_OK;
+}
+
+}  // namespace
+
+extern "C" int rihip_ip_index_create(int d, void** handle) {
+  RIHIP_REQUIRE(handle, RIHIP_ERR_ARG, "ip_index_create: null handle");
+  RIHIP_REQUIRE(d == 32 || d == 64 || d == 128, RIHIP_ERR_SHAPE, "ip_index_create: unsupported embed_dim=%d (32/64/128)", d);
+  IpIndex* h = new IpIndex();
+  h->d = d;
+  *handle = h;
+  return RIHIP_OK;
+}
+
+extern "C" int rihip_ip_index_destroy(void* handle) {
+  IpIndex* h = (IpIndex*)handle;
+  if (!h) return RIHIP_OK;
+  free_index_arrays(h);
+  h->cand.release(); h->scand.release(); h->fcand.release(); h->count.release(); h->fail_flags.release();
+  h->fail_list.release(); h->n_fail.release(); h->fcount.release(); h->thr.release(); h->fQ.release();
+  h->probe_bits.release();
+  if (h->h_nfail) hipHostFree(h->h_nfail);
+  delete h;
+  return RIHIP_OK;
+}
+
+// Replace the index content with N vectors (host or device pointer; copied, caller keeps ownership).
+extern "C" int rihip_ip_index_set_vectors(void* handle, const float* X, int64_t N, int x_on_device, void* stream) {
+  IpIndex* h = (IpIndex*)handle;
+  RIHIP_REQUIRE(h && X && N > 0 && N < (1ll << 31), RIHIP_ERR_ARG, "ip_index_set_vectors: bad arguments");
+  free_index_arrays(h);
+  HIPCHK(hipMalloc((void**)&h->X, sizeof(float) * (size_t)N * h->d));
+  HIPCHK(hipMemcpyAsync(h->X, X, sizeof(float) * (size_t)N * h->d, x_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                        (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  h->N = N;
+  return RIHIP_OK;
+}
+
+extern "C" int64_t rihip_ip_index_ntotal(void* handle) { return handle ? ((IpIndex*)handle)->N : 0; }
+extern "C" int rihip_ip_index_is_ivf(void* handle) { return handle ? (((IpIndex*)handle)->ivf ? 1 : 0) : 0; }
+extern "C" int rihip_ip_index_max_k(void) { return K_MAX; }
+
+extern "C" int rihip_ip_index_set_nprobe(void* handle, int nprobe) {
+  IpIndex* h = (IpIndex*)handle;
+  RIHIP_REQUIRE(h && nprobe >= 1, RIHIP_ERR_ARG, "ip_index_set_nprobe: bad arguments");
+  h->nprobe = nprobe;
+  return RIHIP_OK;
+}
+
+// queries: device [nq,d]; outputs: device scores f32[nq,k] (desc, -inf pad), rows i64[nq,k] (-1 pad)
+extern "C" int rihip_ip_index_search(void* handle, const float* Q, int64_t nq, int k, float* out_scores,
+                                     int64_t* out_rows, void* stream) {
+  IpIndex* h = (IpIndex*)handle;
+  RIHIP_REQUIRE(h && h->X && h->N > 0, RIHIP_ERR_STATE, "ip_index_search: index is empty");
+  RIHIP_REQUIRE(Q && out_scores && out_rows && nq > 0, RIHIP_ERR_ARG, "ip_index_search: bad arguments");
+  RIHIP_REQUIRE(k >= 1 && k <= K_MAX, RIHIP_ERR_ARG, "ip_index_search: k=%d outside [1,%d]", k, K_MAX);
+  RIHIP_REQUIRE((reinterpret_cast<uintptr_t>(Q) & 15) == 0, RIHIP_ERR_ARG, "ip_index_search: Q must be 16-byte aligned");
+  const int64_t CH = 4096;  // queries per internal pass (bounds scratch)
+  for (int64_t q0 = 0; q0 < nq; q0 += CH) {
+    const int64_t n = (nq - q0 < CH) ? nq - q0 : CH;
+    int rc = search_chunk(h, Q + q0 * h->d, n, k, out_scores + q0 * k, out_rows + q0 * k, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return RIHIP_OK;
+}
+
+extern "C" int rihip_map_rows_to_ids(int64_t* rows, int64_t n, const int64_t* item_ids, void* stream) {
+  RIHIP_REQUIRE(rows && item_ids && n >= 0, RIHIP_ERR_ARG, "map_rows_to_ids: bad arguments");
+  if (n == 0) return RIHIP_OK;
+  hipLaunchKernelGGL(map_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows, n, item_ids);
+  RIHIP_CHECK_LAUNCH();
+  return RIHIP_OK;
+}
+
+// k-means (IP assignment, mean update) + list-contiguous re-ordering.  Deterministic given seed.
+extern "C" int rihip_ip_index_train_ivf(void* handle, int nlist, int n_iter, uint64_t seed, void* stream) {
+  IpIndex* h = (IpIndex*)handle;
+  RIHIP_REQUIRE(h && h->X && !h->ivf, RIHIP_ERR_STATE, "ip_index_train_ivf: needs a flat, non-empty index");
+  RIHIP_REQUIRE(nlist >= 1 && nlist <= h->N, RIHIP_ERR_ARG, "ip_index_train_ivf: nlist=%d for N=%lld", nlist, (long long)h->N);
+  const int d = h->d;
+  RIHIP_REQUIRE((size_t)nlist * d * 4 + nlist * 4 <= 64 * 1024, RIHIP_ERR_SHAPE,
+                "ip_index_train_ivf: nlist*d*4 must fit 64 KiB of LDS (nlist=%d, d=%d)", nlist, d);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t N = h->N;
+  // initial centroids: nlist distinct rows picked by a seeded LCG over a strided lattice
+  std::vector<int64_t> pick(nlist);
+  {
+    uint64_t s = rihip_splitmix64(seed);
+    const int64_t step = N / nlist;
+    for (int c = 0; c < nlist; ++c) { s = rihip_splitmix64(s); pick[c] = (int64_t)c * step + (int64_t)(s % (uint64_t)step); }
+  }
+  HIPCHK(hipMalloc((void**)&h->C, sizeof(float) * nlist * d));
+  for (int c = 0; c < nlist; ++c)
+    HIPCHK(hipMemcpyAsync(h->C + (size_t)c * d, h->X + (size_t)pick[c] * d, sizeof(float) * d, hipMemcpyDeviceToDevice, st));
+  int* assign = nullptr; float* slab = nullptr; int* cnt_slab = nullptr; int* counts = nullptr;
+  const int NSL = 256;
+  HIPCHK(hipMalloc((void**)&assign, sizeof(int) * N));
+  HIPCHK(hipMalloc((void**)&slab, sizeof(float) * (size_t)NSL * nlist * d));
+  HIPCHK(hipMalloc((void**)&cnt_slab, sizeof(int) * (size_t)NSL * nlist));
+  HIPCHK(hipMalloc((void**)&counts, sizeof(int) * nlist));
+  const size_t lds_c = sizeof(float) * nlist * d;
+  const int agrid = (int)((N + 3) / 4 < 2048 ? (N + 3) / 4 : 2048);
+  for (int it = 0; it <= n_iter; ++it) {
+    hipLaunchKernelGGL(ivf_assign_kernel, dim3(agrid), dim3(256), lds_c, st, h->X, N, d, h->C, nlist, assign);
+    hipLaunchKernelGGL(ivf_accum_kernel, dim3(NSL), dim3(256), lds_c + sizeof(int) * nlist, st, h->X, N, d, assign, nlist, slab, cnt_slab);
+    if (it == n_iter) {  // final assignment: only the counts are needed
+      hipLaunchKernelGGL(ivf_update_kernel, dim3((nlist * d + 255) / 256), dim3(256), 0, st, slab, cnt_slab, NSL, nlist, d, h->C, counts, 0);
+      break;
+    }
+    hipLaunchKernelGGL(ivf_update_kernel, dim3((nlist * d + 255) / 256), dim3(256), 0, st, slab, cnt_slab, NSL, nlist, d, h->C, counts, 1);
+  }
+  {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { rihip_set_error("ivf train launch: %s", hipGetErrorString(e)); return RIHIP_ERR_HIP; }
+  }
+  // host-side list layout (N ints; build-time only)
+  std::vector<int> h_assign(N), h_counts(nlist);
+  HIPCHK(hipMemcpyAsync(h_assign.data(), assign, sizeof(int) * N, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(h_counts.data(), counts, sizeof(int) * nlist, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  std::vector<int64_t> off(nlist + 1, 0);
+  h->list_len.assign(nlist, 0);
+  for (int c = 0; c < nlist; ++c) {
+    h->list_len[c] = h_counts[c];
+    off[c + 1] = off[c] + ((int64_t)h_counts[c] + TR - 1) / TR * TR;
+  }
+  const int64_t Np = off[nlist] > 0 ? off[nlist] : TR;
+  std::vector<int64_t> rid(Np, -1);
+  std::vector<int> tl(Np / TR, 0);
+  {
+    std::vector<int64_t> cur(off.begin(), off.end() - 1);
+    for (int64_t r = 0; r < N; ++r) rid[cur[h_assign[r]]++] = r;  // ascending original row inside a list
+    for (int c = 0; c < nlist; ++c)
+      for (int64_t t = off[c] / TR; t < off[c + 1] / TR; ++t) tl[t] = c;
+  }
+  float* Xn = nullptr;
+  HIPCHK(hipMalloc((void**)&Xn, sizeof(float) * (size_t)Np * d));
+  HIPCHK(hipMemsetAsync(Xn, 0, sizeof(float) * (size_t)Np * d, st));
+  HIPCHK(hipMalloc((void**)&h->row_ids, sizeof(int64_t) * Np));
+  HIPCHK(hipMalloc((void**)&h->tile_list, sizeof(int) * (Np / TR)));
+  HIPCHK(hipMemcpyAsync(h->row_ids, rid.data(), sizeof(int64_t) * Np, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(h->tile_list, tl.data(), sizeof(int) * (Np / TR), hipMemcpyHostToDevice, st));
+  // permute rows on device: contiguous runs per list are copied row by row via a gather kernel
+  {
+    std::vector<int> src(Np);
+    for (int64_t i = 0; i < Np; ++i) src[i] = rid[i] >= 0 ? (int)rid[i] : -1;
+    int* d_src = nullptr;
+    HIPCHK(hipMalloc((void**)&d_src, sizeof(int) * Np));
+    HIPCHK(hipMemcpyAsync(d_src, src.data(), sizeof(int) * Np, hipMemcpyHostToDevice, st));
+    // reuse gather_rows_kernel for valid rows: padding rows (src=-1) are remapped to row 0 then zeroed by row_ids=-1 filter
+    for (int64_t i = 0; i < Np; ++i) if (src[i] < 0) src[i] = 0;
+    HIPCHK(hipMemcpyAsync(d_src, src.data(), sizeof(int) * Np, hipMemcpyHostToDevice, st));
+    const int64_t tot = Np * d;
+    for (int64_t o = 0; o < Np; o += (1 << 20)) {
+      const int64_t n = (Np - o < (1 << 20)) ? Np - o : (1 << 20);
+      hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n * d + 255) / 256)), dim3(256), 0, st, h->X, d_src + o, (int)n, d, Xn + o * d);
+    }
+    (void)tot;
+    HIPCHK(hipStreamSynchronize(st));
+    hipFree(d_src);
+  }
+  hipFree(assign); hipFree(slab); hipFree(cnt_slab); hipFree(counts);
+  hipFree(h->X);
+  h->X = Xn; h->Np = Np; h->nlist = nlist; h->ivf = true;
+  return RIHIP_OK;
+}
+
+// ---- persistence: own binary format ("RIHIPIDX" v1); the .meta.pkl sidecar stays with the Python wrapper
+extern "C" int rihip_ip_index_save(void* handle, const char* path) {
+  IpIndex* h = (IpIndex*)handle;
+  RIHIP_REQUIRE(h && h->X && path, RIHIP_ERR_STATE, "ip_index_save: empty index");
+  FILE* f = fopen(path, "wb");
+  RIHIP_REQUIRE(f, RIHIP_ERR_IO, "ip_index_save: cannot open %s", path);
+  const int64_t rows = h->ivf ? h->Np : h->N;
+  std::vector<float> X((size_t)rows * h->d);
+  hipMemcpy(X.data(), h->X, sizeof(float) * X.size(), hipMemcpyDeviceToHost);
+  const char magic[8] = {'R', 'I', 'H', 'I', 'P', 'I', 'D', 'X'};
+  int64_t hdr[8] = {1, h->d, h->N, h->ivf ? 1 : 0, h->nlist, h->nprobe, h->Np, 0};
+  fwrite(magic, 1, 8, f); fwrite(hdr, sizeof(int64_t), 8, f); fwrite(X.data(), sizeof(float), X.size(), f);
+  if (h->ivf) {
+    std::vector<float> C((size_t)h->nlist * h->d); std::vector<int> tl(h->Np / TR); std::vector<int64_t> rid(h->Np);
+    hipMemcpy(C.data(), h->C, sizeof(float) * C.size(), hipMemcpyDeviceToHost);
+    hipMemcpy(tl.data(), h->tile_list, sizeof(int) * tl.size(), hipMemcpyDeviceToHost);
+    hipMemcpy(rid.data(), h->row_ids, sizeof(int64_t) * rid.size(), hipMemcpyDeviceToHost);
+    fwrite(C.data(), sizeof(float), C.size(), f); fwrite(tl.data(), sizeof(int), tl.size(), f);
+    fwrite(rid.data(), sizeof(int64_t), rid.size(), f); fwrite(h->list_len.data(), sizeof(int64_t), h->nlist, f);
+  }
+  const bool ok = !ferror(f);
+  fclose(f);
+  RIHIP_REQUIRE(ok, RIHIP_ERR_IO, "ip_index_save: write error on %s", path);
+  return RIHIP_OK;
+}
+
+extern "C" int rihip_ip_index_load(const char* path, void** handle) {
+  RIHIP_REQUIRE(path && handle, RIHIP_ERR_ARG, "ip_index_load: bad arguments");
+  FILE* f = fopen(path, "rb");
+  RIHIP_REQUIRE(f, RIHIP_ERR_IO, "ip_index_load: cannot open %s", path);
+  char magic[8]; int64_t hdr[8];
+  if (fread(magic, 1, 8, f) != 8 || memcmp(magic, "RIHIPIDX", 8) != 0 || fread(hdr, sizeof(int64_t), 8, f) != 8 || hdr[0] != 1) {
+    fclose(f); rihip_set_error("ip_index_load: %s is not a RIHIPIDX v1 file", path); return RIHIP_ERR_IO;
+  }
+  IpIndex* h = new IpIndex();
+  h->d = (int)hdr[1]; h->N = hdr[2]; h->ivf = hdr[3] != 0; h->nlist = (int)hdr[4]; h->nprobe = (int)hdr[5]; h->Np = hdr[6];
+  const int64_t rows = h->ivf ? h->Np : h->N;
+  std::vector<float> X((size_t)rows * h->d);
+  bool ok = fread(X.data(), sizeof(float), X.size(), f) == X.size();
+  if (ok) { ok = hipMalloc((void**)&h->X, sizeof(float) * X.size()) == hipSuccess && hipMemcpy(h->X, X.data(), sizeof(float) * X.size(), hipMemcpyHostToDevice) == hipSuccess; }
+  if (ok && h->ivf) {
+    std::vector<float> C((size_t)h->nlist * h->d); std::vector<int> tl(h->Np / TR); std::vector<int64_t> rid(h->Np);
+    h->list_len.assign(h->nlist, 0);
+    ok = fread(C.data(), sizeof(float), C.size(), f) == C.size() && fread(tl.data(), sizeof(int), tl.size(), f) == tl.size() &&
+         fread(rid.data(), sizeof(int64_t), rid.size(), f) == rid.size() &&
+         fread(h->list_len.data(), sizeof(int64_t), h->nlist, f) == (size_t)h->nlist;
+    if (ok) ok = hipMalloc((void**)&h->C, sizeof(float) * C.size()) == hipSuccess && hipMalloc((void**)&h->tile_list, sizeof(int) * tl.size()) == hipSuccess &&
+                 hipMalloc((void**)&h->row_ids, sizeof(int64_t) * rid.size()) == hipSuccess &&
+                 hipMemcpy(h->C, C.data(), sizeof(float) * C.size(), hipMemcpyHostToDevice) == hipSuccess &&
+                 hipMemcpy(h->tile_list, tl.data(), sizeof(int) * tl.size(), hipMemcpyHostToDevice) == hipSuccess &&
+                 hipMemcpy(h->row_ids, rid.data(), sizeof(int64_t) * rid.size(), hipMemcpyHostToDevice) == hipSuccess;
+  }
+  fclose(f);
+  if (!ok) { rihip_ip_index_destroy(h); rihip_set_error("ip_index_load: truncated file or allocation failure: %s", path); return RIHIP_ERR_IO; }
+  *handle = h;
+  return RIHIP_OK;
+}

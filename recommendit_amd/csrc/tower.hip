@@ -1,0 +1,567 @@
+// Two-Tower MLP kernels for gfx950: fused  gather -> Linear+ReLU+dropout -> Linear -> L2-normalise
+// (forward) and its hand-derived backward, on exact-f32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+// Replaces the bodies of UserTower.forward / ItemTower.forward
+// (reference src/models/two_tower.py:39-42, :68-72) and their autograd backward.
+//
+// Structure (both kernels): one 256-thread workgroup (4 waves, one per SIMD) walks 64-row
+// tiles of the batch (persistent grid-stride loop).  The weight fragments each wave needs as
+// MFMA B-operands are *register-stationary* for the whole kernel (loaded once per wave);
+// only batch rows move through LDS.  Embedding rows are gathered by id as whole rows
+// (256/512-B coalesced float4 segments) straight into the LDS tile.
+//
+// k-permutation: one ds_read_b128 fetches 4 consecutive k of a row; MFMA step s of an 8-wide
+// k-block uses k = 8*kb + 4*(lane>>5) + s for BOTH operands, so A needs one b128 per 4 MFMAs.
+#include "common.h"
+#include "recommendit_hip.h"
+
+namespace {
+
+constexpr int TM = 64;  // batch rows per tile
+
+template <int N>
+struct WaveTiles {  // how the (TM/32) x (N/32) output tiles of a [64 x N] GEMM map to 4 waves
+  static constexpr int CT = N / 32;
+  static constexpr int NR = (CT >= 4) ? 2 : 1;
+  __device__ static __forceinline__ int ct(int w) { return CT >= 4 ? w : (CT == 2 ? (w & 1) : 0); }
+  __device__ static __forceinline__ int rt0(int w) { return CT >= 4 ? 0 : (CT == 2 ? (w >> 1) : w); }
+  __device__ static __forceinline__ bool active(int w) { return CT == 1 ? (w < 2) : true; }
+};
+
+// acc[t] += A[rows of tile rt0+t][k] * Bfrag ; A row-major in LDS (k contiguous)
+template <int KB, int NR>
+__device__ __forceinline__ void gemm_rowA_regB(const float* As, int lda, int rt0, const f32x4 (&bf)[KB],
+                                               f32x16 (&acc)[NR], int lane) {
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+    for (int t = 0; t < NR; ++t) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(&As[((rt0 + t) * 32 + r) * lda + kb * 8 + 4 * h]);
+      acc[t] = mfma32(a.x, bf[kb].x, acc[t]);
+      acc[t] = mfma32(a.y, bf[kb].y, acc[t]);
+      acc[t] = mfma32(a.z, bf[kb].z, acc[t]);
+      acc[t] = mfma32(a.w, bf[kb].w, acc[t]);
+    }
+  }
+}
+
+// B fragment for "out = A . W^T" (W row-major [N][K], k contiguous): lane (j=l&31,h) <- W[ct*32+j][8kb+4h+s]
+template <int KB>
+__device__ __forceinline__ void load_frag_rows(f32x4 (&bf)[KB], const float* __restrict__ W, int ldw, int K, int row,
+                                               int lane) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int k = kb * 8 + 4 * h + s;
+      bf[kb][s] = (k < K) ? W[(size_t)row * ldw + k] : 0.f;
+    }
+  }
+}
+// B fragment for "out = A . W" (W row-major [K][N]): lane (j,h) <- W[8kb+4h+s][col]
+template <int KB>
+__device__ __forceinline__ void load_frag_cols(f32x4 (&bf)[KB], const float* __restrict__ W, int ldw, int col,
+                                               int lane) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) bf[kb][s] = W[(size_t)(kb * 8 + 4 * h + s) * ldw + col];
+  }
+}
+
+struct TowerFwdArgs {
+  const float* table;
+  int64_t n_rows;
+  const int64_t* ids;
+  const float* genres;  // [B,18] or null
+  int64_t B;
+  const float *W1, *b1, *W2, *b2;
+  float* out;    // [B,D]
+  float* hid;    // [B,H] post-dropout hidden (nullable)
+  float* denom;  // [B] max(|y|,eps) (nullable)
+  int training;
+  uint64_t seed_mul;
+  uint32_t thresh24;
+  float scale;      // 1/(1-p)
+  int64_t row0;     // global row offset for the dropout counter
+  int* err_flag;    // set to 1 on out-of-range id (nullable)
+};
+
+template <int D, int K1P, bool ITEM>
+__device__ __forceinline__ void gather_tile(float* Xs, int ldx, const float* __restrict__ table, int64_t n_rows,
+                                            const int64_t* __restrict__ ids, const float* __restrict__ genres,
+                                            int64_t row_base, int64_t B, int tid, int* err_flag) {
+  constexpr int V = D / 4;
+  for (int idx = tid; idx < TM * V; idx += 256) {
+    const int r = idx / V, c4 = idx % V;
+    const int64_t grow = row_base + r;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (grow < B) {
+      int64_t id = ids[grow];
+      if (id < 0 || id >= n_rows) {
+        if (err_flag) *err_flag = 1;
+        id = 0;
+      }
+      v = reinterpret_cast<const f32x4*>(table + (size_t)id * D)[c4];
+    }
+    *reinterpret_cast<f32x4*>(&Xs[r * ldx + c4 * 4]) = v;
+  }
+  if (ITEM) {
+    constexpr int GW = K1P - D;  // 18 genres + zero pad
+    for (int idx = tid; idx < TM * GW; idx += 256) {
+      const int r = idx / GW, c = idx % GW;
+      const int64_t grow = row_base + r;
+      Xs[r * ldx + D + c] = (c < 18 && grow < B) ? genres[grow * 18 + c] : 0.f;
+    }
+  }
+}
+
+template <int D, int H, bool ITEM>
+__global__ __launch_bounds__(256) void tower_fwd_kernel(TowerFwdArgs a) {
+  constexpr int K1 = D + (ITEM ? 18 : 0);
+  constexpr int K1P = (K1 + 7) / 8 * 8;
+  constexpr int LDX = K1P + 4, LDH = H + 4, LDY = D + 4;
+  constexpr int KB1 = K1P / 8, KB2 = H / 8;
+  using T1 = WaveTiles<H>;
+  using T2 = WaveTiles<D>;
+  __shared__ __attribute__((aligned(16))) float Xs[TM * LDX];  // X tile, later aliased by the Y tile
+  __shared__ __attribute__((aligned(16))) float Hs[TM * LDH];
+  static_assert(LDY <= LDX, "Y tile must fit in the X tile");
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int ct1 = T1::ct(w), ct2 = T2::ct(w);
+
+  f32x4 w1f[KB1], w2f[KB2];
+  load_frag_rows<KB1>(w1f, a.W1, K1, K1, ct1 * 32 + (lane & 31), lane);
+  load_frag_rows<KB2>(w2f, a.W2, H, H, ct2 * 32 + (lane & 31), lane);
+  const float b1v = a.b1[ct1 * 32 + (lane & 31)];
+  const float b2v = a.b2[ct2 * 32 + (lane & 31)];
+
+  const int64_t ntiles = (a.B + TM - 1) / TM;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t row_base = tile * TM;
+    gather_tile<D, K1P, ITEM>(Xs, LDX, a.table, a.n_rows, a.ids, a.genres, row_base, a.B, tid, a.err_flag);
+    __syncthreads();
+
+    // ---- Linear 1 + ReLU + dropout -> Hs
+    if (T1::active(w)) {
+      f32x16 acc[T1::NR];
+#pragma unroll
+      for (int t = 0; t < T1::NR; ++t) acc[t] = zero16();
+      gemm_rowA_regB<KB1, T1::NR>(Xs, LDX, T1::rt0(w), w1f, acc, lane);
+      const int col = ct1 * 32 + (lane & 31);
+#pragma unroll
+      for (int t = 0; t < T1::NR; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (T1::rt0(w) + t) * 32 + acc_row(r, lane);
+          const int64_t grow = row_base + row;
+          float v = fmaxf(acc[t][r] + b1v, 0.f);
+          if (a.training) {
+            const bool keep = rihip_keep(a.seed_mul, (uint64_t)(a.row0 + grow) * H + col, a.thresh24);
+            v = keep ? v * a.scale : 0.f;
+          }
+          Hs[row * LDH + col] = v;
+          if (a.hid && grow < a.B) a.hid[grow * H + col] = v;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- Linear 2 -> Ys (aliases Xs; every wave is past its last Xs read)
+    float* Ys = Xs;
+    if (T2::active(w)) {
+      f32x16 acc[T2::NR];
+#pragma unroll
+      for (int t = 0; t < T2::NR; ++t) acc[t] = zero16();
+      gemm_rowA_regB<KB2, T2::NR>(Hs, LDH, T2::rt0(w), w2f, acc, lane);
+      const int col = ct2 * 32 + (lane & 31);
+#pragma unroll
+      for (int t = 0; t < T2::NR; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (T2::rt0(w) + t) * 32 + acc_row(r, lane);
+          Ys[row * LDY + col] = acc[t][r] + b2v;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- row L2-normalise: 4 threads per row, coalesced float4 stores
+    {
+      const int row = tid >> 2, q = tid & 3;
+      constexpr int V = D / 16;  // float4 per thread
+      f32x4 y[V];
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        y[i] = *reinterpret_cast<const f32x4*>(&Ys[row * LDY + (q * V + i) * 4]);
+        ss += y[i].x * y[i].x + y[i].y * y[i].y + y[i].z * y[i].z + y[i].w * y[i].w;
+      }
+      ss += __shfl_xor(ss, 1, 64);
+      ss += __shfl_xor(ss, 2, 64);
+      const float dn = fmaxf(sqrtf(ss), 1e-12f);
+      const int64_t grow = row_base + row;
+      if (grow < a.B) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          f32x4 o = {y[i].x / dn, y[i].y / dn, y[i].z / dn, y[i].w / dn};
+          reinterpret_cast<f32x4*>(a.out + grow * D)[q * V + i] = o;
+        }
+        if (q == 0 && a.denom) a.denom[grow] = dn;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// -----------------------------------------------------------------------------------------
+// Backward
+// -----------------------------------------------------------------------------------------
+struct TowerBwdArgs {
+  const float* table;
+  int64_t n_rows;
+  const int64_t* ids;
+  const float* genres;
+  int64_t B;
+  const float *W1, *W2;
+  const float* gout;   // [B,D] dL/d out
+  const float* out;    // [B,D]
+  const float* denom;  // [B]
+  const float* hid;    // [B,H]
+  float scale;         // dropout 1/(1-p) (1 when not training)
+  float* dX;           // [B,D] per-sample embedding-row grads
+  float* slab;         // [grid][P] partial weight grads, P = H*K1 + H + D*H + D
+};
+
+template <int D, int H, bool ITEM>
+__global__ __launch_bounds__(256) void tower_bwd_kernel(TowerBwdArgs a) {
+  constexpr int K1 = D + (ITEM ? 18 : 0);
+  constexpr int K1P = (K1 + 7) / 8 * 8;
+  constexpr int LDX = K1P + 4, LDH = H + 4, LDG = D + 4;
+  constexpr int CTD = D / 32, CTH = H / 32, NX = (K1P + 31) / 32;
+  using TH = WaveTiles<H>;  // dh  = Gy . W2   [64 x H]
+  using TD = WaveTiles<D>;  // dx  = dPre . W1 [64 x D]
+  // dW2 [D x H] tiles: T2 = CTD*CTH, TPW2 per wave, all of a wave's tiles share the D-tile
+  constexpr int T2 = CTD * CTH;
+  constexpr int TPW2 = (T2 >= 4) ? T2 / 4 : 1;
+  // dW1 [H x K1P] tiles: CTH x NX; CTH==4: wave w owns h-tile w and all NX x-tiles;
+  // CTH==2: wave w owns h-tile (w&1) and x-tiles (w>>1), (w>>1)+2, ...
+  constexpr int TPW1 = (CTH == 4) ? NX : (NX + 1) / 2;
+
+  __shared__ __attribute__((aligned(16))) float Xs[TM * LDX + 32];  // +32: partial last x-tile over-read
+  __shared__ __attribute__((aligned(16))) float Hs[TM * LDH];       // hid tile, then dPre tile
+  __shared__ __attribute__((aligned(16))) float Gs[TM * LDG];       // gy tile
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r31 = lane & 31, hh = lane >> 5;
+
+  // register-stationary B fragments
+  f32x4 w2b[D / 8];  // dh = Gy . W2 : B[k=d][j=h] = W2[k][cth*32+j]
+  f32x4 w1b[H / 8];  // dx = dPre . W1[:, :D] : B[k=h][j=x] = W1[k][ctx*32+j]
+  load_frag_cols<D / 8>(w2b, a.W2, H, TH::ct(w) * 32 + r31, lane);
+  load_frag_cols<H / 8>(w1b, a.W1, K1, TD::ct(w) * 32 + r31, lane);
+
+  // persistent weight-grad accumulators
+  f32x16 aW2[TPW2], aW1[TPW1];
+#pragma unroll
+  for (int t = 0; t < TPW2; ++t) aW2[t] = zero16();
+#pragma unroll
+  for (int t = 0; t < TPW1; ++t) aW1[t] = zero16();
+  float ab1 = 0.f, ab2 = 0.f;  // thread tid<H owns db1[tid]; tid<D owns db2[tid]
+
+  const bool w2_active = (w * TPW2) < T2;
+  const int ctd2 = (w * TPW2) / CTH, cth2_0 = (w * TPW2) % CTH;
+  const int cth1 = (CTH == 4) ? w : (w & 1);
+  const int ctx1_0 = (CTH == 4) ? 0 : (w >> 1);
+  constexpr int ctx1_step = (CTH == 4) ? 1 : 2;
+
+  const int64_t ntiles = (a.B + TM - 1) / TM;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t row_base = tile * TM;
+    // ---- stage: gy (normalise backward), hid, gathered x
+    {
+      const int row = tid >> 2, q = tid & 3;
+      constexpr int V = D / 16;
+      const int64_t grow = row_base + row;
+      f32x4 g[V], o[V];
+      float dot = 0.f;
+      float dn = 1.f;
+      if (grow < a.B) {
+        dn = a.denom[grow];
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          g[i] = reinterpret_cast<const f32x4*>(a.gout + grow * D)[q * V + i];
+          o[i] = reinterpret_cast<const f32x4*>(a.out + grow * D)[q * V + i];
+          dot += g[i].x * o[i].x + g[i].y * o[i].y + g[i].z * o[i].z + g[i].w * o[i].w;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          g[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+          o[i] = g[i];
+        }
+      }
+      dot += __shfl_xor(dot, 1, 64);
+      dot += __shfl_xor(dot, 2, 64);
+      if (dn <= 1e-12f) dot = 0.f;  // clamp branch of F.normalize: out = y/eps, d out/dy = 1/eps
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        f32x4 gy = {(g[i].x - o[i].x * dot) / dn, (g[i].y - o[i].y * dot) / dn, (g[i].z - o[i].z * dot) / dn,
+                    (g[i].w - o[i].w * dot) / dn};
+        *reinterpret_cast<f32x4*>(&Gs[row * LDG + (q * V + i) * 4]) = gy;
+      }
+    }
+    for (int idx = tid; idx < TM * (H / 4); idx += 256) {
+      const int r = idx / (H / 4), c4 = idx % (H / 4);
+      const int64_t grow = row_base + r;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (grow < a.B) v = reinterpret_cast<const f32x4*>(a.hid + grow * H)[c4];
+      *reinterpret_cast<f32x4*>(&Hs[r * LDH + c4 * 4]) = v;
+    }
+    gather_tile<D, K1P, ITEM>(Xs, LDX, a.table, a.n_rows, a.ids, a.genres, row_base, a.B, tid, nullptr);
+    __syncthreads();
+
+    // ---- db2 += colsum(gy) ; dW2 += gy^T . hid
+    if (tid < D) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < TM; ++r) s += Gs[r * LDG + tid];
+      ab2 += s;
+    }
+    if (w2_active) {
+#pragma unroll 4
+      for (int s = 0; s < 32; ++s) {
+        const int row = 2 * s + hh;
+        const float av = Gs[row * LDG + ctd2 * 32 + r31];
+#pragma unroll
+        for (int t = 0; t < TPW2; ++t) {
+          const float bv = Hs[row * LDH + (cth2_0 + t) * 32 + r31];
+          aW2[t] = mfma32(av, bv, aW2[t]);
+        }
+      }
+    }
+    // ---- dh = gy . W2  (accumulators only; Hs is overwritten after the barrier)
+    f32x16 dh[TH::NR];
+#pragma unroll
+    for (int t = 0; t < TH::NR; ++t) dh[t] = zero16();
+    if (TH::active(w)) gemm_rowA_regB<D / 8, TH::NR>(Gs, LDG, TH::rt0(w), w2b, dh, lane);
+    __syncthreads();
+    if (TH::active(w)) {
+      const int col = TH::ct(w) * 32 + r31;
+#pragma unroll
+      for (int t = 0; t < TH::NR; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (TH::rt0(w) + t) * 32 + acc_row(r, lane);
+          const float hv = Hs[row * LDH + col];
+          Hs[row * LDH + col] = (hv > 0.f) ? dh[t][r] * a.scale : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- db1 += colsum(dPre) ; dW1 += dPre^T . x ; dx = dPre . W1[:, :D]
+    if (tid < H) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < TM; ++r) s += Hs[r * LDH + tid];
+      ab1 += s;
+    }
+#pragma unroll 4
+    for (int s = 0; s < 32; ++s) {
+      const int row = 2 * s + hh;
+      const float av = Hs[row * LDH + cth1 * 32 + r31];
+#pragma unroll
+      for (int t = 0; t < TPW1; ++t) {
+        const int ctx = ctx1_0 + t * ctx1_step;
+        if (ctx < NX) {
+          const float bv = Xs[row * LDX + ctx * 32 + r31];
+          aW1[t] = mfma32(av, bv, aW1[t]);
+        }
+      }
+    }
+    if (TD::active(w)) {
+      f32x16 dx[TD::NR];
+#pragma unroll
+      for (int t = 0; t < TD::NR; ++t) dx[t] = zero16();
+      gemm_rowA_regB<H / 8, TD::NR>(Hs, LDH, TD::rt0(w), w1b, dx, lane);
+      const int col = TD::ct(w) * 32 + r31;
+#pragma unroll
+      for (int t = 0; t < TD::NR; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t grow = row_base + (TD::rt0(w) + t) * 32 + acc_row(r, lane);
+          if (grow < a.B) a.dX[grow * D + col] = dx[t][r];
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- write this workgroup's partial weight grads: slab = [dW1 (H*K1) | db1 (H) | dW2 (D*H) | db2 (D)]
+  constexpr int P = H * K1 + H + D * H + D;
+  float* sl = a.slab + (size_t)blockIdx.x * P;
+#pragma unroll
+  for (int t = 0; t < TPW1; ++t) {
+    const int ctx = ctx1_0 + t * ctx1_step;
+    if (ctx < NX) {
+      const int xc = ctx * 32 + r31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int hr = cth1 * 32 + acc_row(r, lane);
+        if (xc < K1) sl[hr * K1 + xc] = aW1[t][r];
+      }
+    }
+  }
+  if (tid < H) sl[H * K1 + tid] = ab1;
+  if (w2_active) {
+#pragma unroll
+    for (int t = 0; t < TPW2; ++t) {
+      const int hc = (cth2_0 + t) * 32 + r31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int dr = ctd2 * 32 + acc_row(r, lane);
+        sl[H * K1 + H + dr * H + hc] = aW2[t][r];
+      }
+    }
+  }
+  if (tid < D) sl[H * K1 + H + D * H + tid] = ab2;
+}
+
+// grads (+)= sum over slabs; one pass, deterministic order
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, int nslab, int P, int H, int K1, int D, float* dW1,
+                                   float* db1, float* dW2, float* db2, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  float s = 0.f;
+  for (int k = 0; k < nslab; ++k) s += slab[(size_t)k * P + i];
+  float* dst;
+  int off;
+  if (i < H * K1) { dst = dW1; off = i; }
+  else if (i < H * K1 + H) { dst = db1; off = i - H * K1; }
+  else if (i < H * K1 + H + D * H) { dst = dW2; off = i - H * K1 - H; }
+  else { dst = db2; off = i - H * K1 - H - D * H; }
+  dst[off] = accumulate ? dst[off] + s : s;
+}
+
+// dense embedding grad: grad[ids[b]] += dX[b]  (padding row 0 gets no gradient)
+__global__ void scatter_add_rows_kernel(float* __restrict__ grad, int64_t n_rows, const int64_t* __restrict__ ids,
+                                        const float* __restrict__ dX, int64_t B, int D) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * D) return;
+  const int64_t b = i / D;
+  const int c = (int)(i % D);
+  const int64_t id = ids[b];
+  if (id <= 0 || id >= n_rows) return;
+  atomicAdd(&grad[id * D + c], dX[i]);
+}
+
+template <int D, int H>
+int launch_fwd(bool item, const TowerFwdArgs& a, int grid, hipStream_t st) {
+  if (item) hipLaunchKernelGGL((tower_fwd_kernel<D, H, true>), dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((tower_fwd_kernel<D, H, false>), dim3(grid), dim3(256), 0, st, a);
+  return 0;
+}
+template <int D, int H>
+int launch_bwd(bool item, const TowerBwdArgs& a, int grid, hipStream_t st) {
+  if (item) hipLaunchKernelGGL((tower_bwd_kernel<D, H, true>), dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((tower_bwd_kernel<D, H, false>), dim3(grid), dim3(256), 0, st, a);
+  return 0;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int rihip_tower_supported(int d, int hidden) {
+  return (d == 32 && hidden == 64) || (d == 64 && hidden == 128) || (d == 128 && hidden == 128) ||
+         (d == 64 && hidden == 64) || (d == 32 && hidden == 128);
+}
+
+#define DISPATCH_DH(FN, ...)                                         \
+  if (d == 32 && hidden == 64) FN<32, 64>(__VA_ARGS__);              \
+  else if (d == 64 && hidden == 128) FN<64, 128>(__VA_ARGS__);       \
+  else if (d == 128 && hidden == 128) FN<128, 128>(__VA_ARGS__);     \
+  else if (d == 64 && hidden == 64) FN<64, 64>(__VA_ARGS__);         \
+  else if (d == 32 && hidden == 128) FN<32, 128>(__VA_ARGS__);
+
+extern "C" int rihip_tower_forward(const float* table, int64_t n_rows, const int64_t* ids, const float* genres,
+                                   int64_t B, int d, int hidden, const float* W1, const float* b1, const float* W2,
+                                   const float* b2, int training, float dropout_p, uint64_t seed, int64_t row0,
+                                   float* out, float* hid, float* denom, int* err_flag, void* stream) {
+  RIHIP_REQUIRE(rihip_tower_supported(d, hidden), RIHIP_ERR_SHAPE,
+                "tower_forward: unsupported (embed_dim=%d, hidden_dim=%d)", d, hidden);
+  RIHIP_REQUIRE(B >= 0 && n_rows > 0, RIHIP_ERR_ARG, "tower_forward: bad sizes B=%lld n_rows=%lld", (long long)B,
+                (long long)n_rows);
+  RIHIP_REQUIRE(table && ids && W1 && b1 && W2 && b2 && out, RIHIP_ERR_ARG, "tower_forward: null pointer");
+  RIHIP_REQUIRE(aligned16(table) && aligned16(out) && (!hid || aligned16(hid)), RIHIP_ERR_ARG,
+                "tower_forward: table/out/hid must be 16-byte aligned");
+  RIHIP_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, RIHIP_ERR_ARG, "tower_forward: dropout_p=%f", dropout_p);
+  if (B == 0) return RIHIP_OK;
+  TowerFwdArgs a;
+  a.table = table; a.n_rows = n_rows; a.ids = ids; a.genres = genres; a.B = B;
+  a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.out = out; a.hid = hid; a.denom = denom;
+  a.training = (training && dropout_p > 0.f) ? 1 : 0;
+  a.seed_mul = rihip_seed_mul(seed); a.thresh24 = rihip_thresh24(dropout_p);
+  a.scale = 1.f / (1.f - dropout_p); a.row0 = row0; a.err_flag = err_flag;
+  const int64_t ntiles = (B + TM - 1) / TM;
+  const int grid = (int)(ntiles < 2 * RIHIP_NCU ? ntiles : 2 * RIHIP_NCU);
+  const bool item = genres != nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_DH(launch_fwd, item, a, grid, st)
+  RIHIP_CHECK_LAUNCH();
+  return RIHIP_OK;
+}
+
+extern "C" int64_t rihip_tower_backward_workspace_floats(int64_t B, int d, int hidden, int item) {
+  const int K1 = d + (item ? 18 : 0);
+  const int64_t P = (int64_t)hidden * K1 + hidden + (int64_t)d * hidden + d;
+  const int64_t ntiles = (B + TM - 1) / TM;
+  const int64_t grid = ntiles < RIHIP_NCU ? ntiles : RIHIP_NCU;
+  return (grid > 0 ? grid : 1) * P;
+}
+
+extern "C" int rihip_tower_backward(const float* table, int64_t n_rows, const int64_t* ids, const float* genres,
+                                    int64_t B, int d, int hidden, const float* W1, const float* W2,
+                                    const float* grad_out, const float* out, const float* denom, const float* hid,
+                                    float dropout_scale, float* dX, float* dW1, float* db1, float* dW2, float* db2,
+                                    int accumulate, float* workspace, void* stream) {
+  RIHIP_REQUIRE(rihip_tower_supported(d, hidden), RIHIP_ERR_SHAPE,
+                "tower_backward: unsupported (embed_dim=%d, hidden_dim=%d)", d, hidden);
+  RIHIP_REQUIRE(table && ids && W1 && W2 && grad_out && out && denom && hid && dX && dW1 && db1 && dW2 && db2 &&
+                    workspace,
+                RIHIP_ERR_ARG, "tower_backward: null pointer");
+  RIHIP_REQUIRE(aligned16(table) && aligned16(grad_out) && aligned16(out) && aligned16(hid), RIHIP_ERR_ARG,
+                "tower_backward: table/grad_out/out/hid must be 16-byte aligned");
+  if (B <= 0) return RIHIP_OK;
+  TowerBwdArgs a;
+  a.table = table; a.n_rows = n_rows; a.ids = ids; a.genres = genres; a.B = B; a.W1 = W1; a.W2 = W2;
+  a.gout = grad_out; a.out = out; a.denom = denom; a.hid = hid; a.scale = dropout_scale; a.dX = dX; a.slab = workspace;
+  const int64_t ntiles = (B + TM - 1) / TM;
+  const int grid = (int)(ntiles < RIHIP_NCU ? ntiles : RIHIP_NCU);
+  const bool item = genres != nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_DH(launch_bwd, item, a, grid, st)
+  RIHIP_CHECK_LAUNCH();
+  const int K1 = d + (item ? 18 : 0);
+  const int P = hidden * K1 + hidden + d * hidden + d;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((P + 255) / 256), dim3(256), 0, st, workspace, grid, P, hidden, K1, d,
+                     dW1, db1, dW2, db2, accumulate);
+  RIHIP_CHECK_LAUNCH();
+  return RIHIP_OK;
+}
+
+extern "C" int rihip_embedding_scatter_add(float* grad_table, int64_t n_rows, const int64_t* ids, const float* dX,
+                                           int64_t B, int d, void* stream) {
+  RIHIP_REQUIRE(grad_table && ids && dX, RIHIP_ERR_ARG, "embedding_scatter_add: null pointer");
+  if (B <= 0) return RIHIP_OK;
+  const int64_t n = B * d;
+  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     grad_table, n_rows, ids, dX, B, d);
+  RIHIP_CHECK_LAUNCH();
+  return RIHIP_OK;
+}

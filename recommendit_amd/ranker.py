@@ -1,0 +1,207 @@
+"""Drop-in LightGBMRanker whose load/predict run in the gfx950 HIP library (no lightgbm).
+
+Mirrors the reference's src/models/ranker.py (:23-249).  ``load`` parses the LightGBM *text*
+model in C++ (rihip_gbdt_load_text) and ``predict`` walks the forest on the GPU, returning the
+raw lambdarank score as float64 like ``Booster.predict`` (ranker.py:174).  ``train``/``save``
+are LightGBM's CPU trainer and stay delegated to the real package when it is importable
+(train is out of scope).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+from pathlib import Path
+from typing import Dict, List, Optional
+
+import numpy as np
+import pandas as pd
+import torch
+
+from . import _lib as L
+
+logger = logging.getLogger(__name__)
+
+try:  # only needed for train()
+    import lightgbm as lgb  # type: ignore
+    LGB_AVAILABLE = True
+except ImportError:
+    lgb = None
+    LGB_AVAILABLE = False
+
+
+class _Forest:
+    """Owns one rihip gbdt handle; method names follow lgb.Booster where callers use them."""
+
+    def __init__(self, handle: int, path: Optional[str] = None):
+        self._h = C.c_void_p(handle)
+        self.path = path
+        self.best_iteration = -1  # a Booster loaded from a model file carries no best_iteration
+
+    def num_trees(self) -> int:
+        return int(L.lib().rihip_gbdt_num_trees(self._h))
+
+    def num_feature(self) -> int:
+        return int(L.lib().rihip_gbdt_num_features(self._h))
+
+    def feature_name(self) -> List[str]:
+        n = int(L.lib().rihip_gbdt_feature_names(self._h, None, 0))
+        buf = C.create_string_buffer(n)
+        L.lib().rihip_gbdt_feature_names(self._h, buf, n)
+        s = buf.value.decode()
+        return s.split("\n") if s else []
+
+    def feature_importance(self, importance_type: str = "split") -> np.ndarray:
+        out = np.zeros(self.num_feature(), dtype=np.float64)
+        L.check(L.lib().rihip_gbdt_feature_importance(self._h, 0 if importance_type == "split" else 1,
+                                                      out.ctypes.data_as(C.c_void_p)), "gbdt_feature_importance")
+        return out.astype(np.int64) if importance_type == "split" else out
+
+    def predict_device(self, X: torch.Tensor) -> torch.Tensor:
+        """X f32 [n, >=n_features] on device -> f64 [n] on device."""
+        X = X.to(dtype=torch.float32).contiguous()
+        out = torch.empty((X.shape[0],), dtype=torch.float64, device=X.device)
+        L.check(L.lib().rihip_gbdt_predict(self._h, X.data_ptr(), X.shape[0], X.shape[1], out.data_ptr(),
+                                           L.stream_ptr()), "gbdt_predict")
+        return out
+
+    def predict(self, X: np.ndarray) -> np.ndarray:
+        Xd = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32)).to(L.device())
+        return self.predict_device(Xd).cpu().numpy()
+
+    def __del__(self):
+        try:
+            if self._h:
+                L.lib().rihip_gbdt_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class LightGBMRanker:
+    def __init__(self, num_leaves: int = 63, n_estimators: int = 500, learning_rate: float = 0.05,
+                 eval_at: List[int] = None):
+        self.num_leaves = num_leaves
+        self.n_estimators = n_estimators
+        self.learning_rate = learning_rate
+        self.eval_at = eval_at or [5, 10, 20]
+        self.model: Optional[_Forest] = None
+        self.feature_names: Optional[List[str]] = None
+        self._trained = False
+        self._text: Optional[str] = None
+
+    # -- training stays LightGBM's CPU trainer (ranker.py:52-155) -------------------------------
+    def train(self, train_df: pd.DataFrame, feature_cols: List[str], label_col: str = "label",
+              query_col: str = "query_id", valid_df: Optional[pd.DataFrame] = None, verbose_eval: int = 50):
+        if not LGB_AVAILABLE:
+            raise ImportError("lightgbm is required for training. Install with: pip install lightgbm "
+                              "(load()/predict() do not need it)")
+        import tempfile
+        self.feature_names = feature_cols
+        X = train_df[feature_cols].values.astype(np.float32)
+        y = train_df[label_col].values.astype(np.float32)
+        groups = train_df.groupby(query_col, sort=False).size().values
+        dtrain = lgb.Dataset(X, label=y, group=groups, feature_name=feature_cols, free_raw_data=False)
+        valid_sets, valid_names = [dtrain], ["train"]
+        if valid_df is not None:
+            Xv = valid_df[feature_cols].values.astype(np.float32)
+            yv = valid_df[label_col].values.astype(np.float32)
+            gv = valid_df.groupby(query_col, sort=False).size().values
+            valid_sets.append(lgb.Dataset(Xv, label=yv, group=gv, feature_name=feature_cols, reference=dtrain,
+                                          free_raw_data=False))
+            valid_names.append("valid")
+        params = {"objective": "lambdarank", "metric": "ndcg", "eval_at": self.eval_at, "num_leaves": self.num_leaves,
+                  "learning_rate": self.learning_rate, "min_child_samples": 20, "subsample": 0.8,
+                  "colsample_bytree": 0.8, "reg_alpha": 0.1, "reg_lambda": 0.1, "label_gain": [0, 1, 3, 7, 15],
+                  "verbose": -1, "n_jobs": -1}
+        evals_result: Dict = {}
+        callbacks = [lgb.log_evaluation(period=verbose_eval), lgb.record_evaluation(evals_result)]
+        if valid_df is not None:
+            callbacks.append(lgb.early_stopping(stopping_rounds=30, verbose=True))
+        booster = lgb.train(params, dtrain, num_boost_round=self.n_estimators, valid_sets=valid_sets,
+                            valid_names=valid_names, callbacks=callbacks)
+        with tempfile.TemporaryDirectory() as td:  # hand the trained forest to the HIP predictor
+            p = str(Path(td) / "m.lgbm")
+            booster.save_model(p)
+            self._text = Path(p).read_text()
+        self._load_text(self._text)
+        self.model.best_iteration = booster.best_iteration
+        self._trained = True
+        return evals_result
+
+    def _load_text(self, text: str) -> None:
+        h = C.c_void_p()
+        b = text.encode()
+        L.check(L.lib().rihip_gbdt_create_from_text(b, len(b), C.byref(h)), "gbdt_create_from_text")
+        self.model = _Forest(h.value)
+
+    # -- inference (ranker.py:161-174) --------------------------------------------------------
+    def predict(self, features_df: pd.DataFrame) -> np.ndarray:
+        if not self._trained or self.model is None:
+            raise RuntimeError("Model not trained. Call train() first.")
+        X = features_df[self.feature_names].values.astype(np.float32)
+        return self.model.predict(X)
+
+    def predict_device(self, X: torch.Tensor) -> torch.Tensor:
+        """Device-resident scoring (not in the reference): X f32 [n, n_features] in feature_names order."""
+        if not self._trained or self.model is None:
+            raise RuntimeError("Model not trained. Call train() first.")
+        return self.model.predict_device(X)
+
+    # -- analysis (ranker.py:180-197) ---------------------------------------------------------
+    def feature_importance(self, importance_type: str = "gain") -> Dict[str, float]:
+        if not self._trained or self.model is None:
+            raise RuntimeError("Model not trained.")
+        importances = self.model.feature_importance(importance_type=importance_type)
+        names = self.model.feature_name()
+        result = dict(zip(names, importances.tolist()))
+        return dict(sorted(result.items(), key=lambda x: x[1], reverse=True))
+
+    def top_features(self, n: int = 10, importance_type: str = "gain") -> Dict[str, float]:
+        imp = self.feature_importance(importance_type)
+        return dict(list(imp.items())[:n])
+
+    # -- persistence (ranker.py:203-226) ------------------------------------------------------
+    def save(self, path: str) -> None:
+        if not self._trained or self.model is None:
+            raise RuntimeError("Model not trained.")
+        save_path = Path(path)
+        save_path.parent.mkdir(parents=True, exist_ok=True)
+        save_path.write_text(self._text)
+        logger.info("Saved ranker to %s", save_path)
+
+    @classmethod
+    def load(cls, path: str) -> "LightGBMRanker":
+        load_path = Path(path)
+        if not load_path.exists():
+            raise FileNotFoundError(f"Ranker model not found at {load_path}")
+        obj = cls()
+        obj._text = load_path.read_text()
+        obj._load_text(obj._text)
+        obj.model.path = str(load_path)
+        obj.feature_names = obj.model.feature_name()
+        obj._trained = True
+        logger.info("Loaded ranker from %s (%d features, %d trees)", load_path, len(obj.feature_names),
+                    obj.model.num_trees())
+        return obj
+
+    @property
+    def n_features(self) -> int:
+        return len(self.feature_names) if self.feature_names else 0
+
+    @property
+    def best_iteration(self) -> int:
+        if self.model is not None:
+            return self.model.best_iteration
+        return 0
+
+    def model_info(self) -> Dict:
+        if not self._trained:
+            return {"status": "not trained"}
+        return {
+            "n_features": self.n_features,
+            "best_iteration": self.best_iteration,
+            "num_leaves": self.num_leaves,
+            "learning_rate": self.learning_rate,
+            "eval_at": self.eval_at,
+            "top_10_features": self.top_features(10) if self._trained else {},
+        }

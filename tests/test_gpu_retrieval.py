@@ -1,0 +1,204 @@
+"""GPU parity: inner-product top-K vs the exact NumPy oracle, plus the reference's own property
+tests for the FAISSIndex wrapper (tests/test_models.py:151-246 of the reference).
+
+Float scores: |score - oracle| <= 2e-6 (unit vectors, exact-f32 fmaf chain vs float64).  Row sets:
+bit-exact whenever the oracle's k-th/(k+1)-th gap exceeds that tolerance; near-ties are checked
+through the score of the returned row instead.  Integer-valued inputs: bit-exact incl. tie-break."""
+import tempfile
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fixtures as fx
+from oracle import retrieval_np as R
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-6
+
+
+def _check_topk(scores, rows, Q, X, k):
+    S = Q.astype(np.float64) @ X.astype(np.float64).T
+    nq = Q.shape[0]
+    assert scores.shape == (nq, k) and rows.shape == (nq, k)
+    ref_sorted = -np.sort(-S, axis=1)[:, :k]
+    np.testing.assert_allclose(scores, ref_sorted, atol=TOL, rtol=0)          # same score multiset
+    assert (np.diff(scores, axis=1) <= 0).all()                               # descending
+    got_true = np.take_along_axis(S, rows, axis=1)
+    np.testing.assert_allclose(scores, got_true, atol=TOL, rtol=0)            # rows carry those scores
+    for q in range(nq):
+        assert len(set(rows[q].tolist())) == k                                # no duplicates
+    # exact set equality where the boundary is not a near-tie
+    ref_sc, ref_rows = R.topk_ip_exact(Q, X, min(k + 1, X.shape[0]))
+    for q in range(nq):
+        if X.shape[0] > k and ref_sc[q, k - 1] - ref_sc[q, k] > 4 * TOL:
+            assert set(rows[q].tolist()) == set(ref_rows[q, :k].tolist()), q
+
+
+def _index(X, exact=True, **kw):
+    from recommendit_amd import FAISSIndex
+    idx = FAISSIndex(embed_dim=X.shape[1], exact=exact, **kw)
+    idx.build_ivf_index(X, list(range(1000, 1000 + X.shape[0])))
+    return idx
+
+
+@pytest.mark.parametrize("N,d,nq,k", [(500, 32, 7, 20), (3883, 64, 130, 500), (70000, 128, 33, 500),
+                                      (200000, 64, 300, 500), (300000, 128, 64, 100)])
+def test_bruteforce_topk_vs_oracle(N, d, nq, k):
+    rng = np.random.RandomState(N)
+    X, Q = fx.unit_rows(rng, N, d), fx.unit_rows(rng, nq, d)
+    idx = _index(X)
+    sc, ids = idx.batch_search(Q, k=k)
+    _check_topk(sc, ids - 1000, Q, X, k)
+
+
+def test_integer_inputs_bit_exact_with_ties():
+    """Small-integer vectors: every dot product is exact in f32, many exact ties -> lowest row wins."""
+    rng = np.random.RandomState(3)
+    N, d, nq, k = 150000, 32, 40, 500
+    X = rng.randint(-2, 3, size=(N, d)).astype(np.float32)
+    Q = rng.randint(-2, 3, size=(nq, d)).astype(np.float32)
+    from recommendit_amd import FAISSIndex
+    idx = FAISSIndex(embed_dim=d, exact=True)
+    idx.build_from_device(torch.from_numpy(X).cuda(), np.arange(N))          # no normalisation
+    sc, rows = idx._search_device(torch.from_numpy(Q).cuda(), k)
+    ref_sc, ref_rows = R.topk_ip_exact_f32(Q, X, k)
+    np.testing.assert_array_equal(sc.cpu().numpy(), ref_sc)
+    np.testing.assert_array_equal(rows.cpu().numpy(), ref_rows)
+
+
+def test_all_identical_rows_take_the_exact_fallback():
+    N, d, k = 70000, 32, 50
+    X = np.tile(fx.unit_rows(np.random.RandomState(0), 1, d), (N, 1))
+    Q = fx.unit_rows(np.random.RandomState(1), 11, d)
+    from recommendit_amd import FAISSIndex
+    idx = FAISSIndex(embed_dim=d, exact=True)
+    idx.build_from_device(torch.from_numpy(X).cuda(), np.arange(N))
+    sc, rows = idx._search_device(torch.from_numpy(Q).cuda(), k)
+    np.testing.assert_array_equal(rows.cpu().numpy(), np.tile(np.arange(k), (11, 1)))
+    assert (sc.cpu().numpy() == sc.cpu().numpy()[:, :1]).all()
+
+
+def test_full_size_corpus_properties():
+    """cfg3 size (N=1M, d=128, k=500): subset of queries checked exactly, all checked for order/validity."""
+    rng = np.random.RandomState(1)
+    N, d, nq, k = 1_000_000, 128, 256, 500
+    X = torch.randn(N, d, generator=torch.Generator().manual_seed(1))
+    X = (X / X.norm(dim=1, keepdim=True)).contiguous()
+    Q = fx.unit_rows(rng, nq, d)
+    from recommendit_amd import FAISSIndex
+    idx = FAISSIndex(embed_dim=d, exact=True)
+    idx.build_from_device(X.cuda(), np.arange(N))
+    sc, rows = idx._search_device(torch.from_numpy(Q).cuda(), k)
+    sc, rows = sc.cpu().numpy(), rows.cpu().numpy()
+    assert (np.diff(sc, axis=1) <= 0).all() and (rows >= 0).all() and (rows < N).all()
+    Xn = X.numpy()
+    _check_topk(sc[:8], rows[:8], Q[:8], Xn, k)
+    # idempotence: searching again gives bit-identical results
+    sc2, rows2 = idx._search_device(torch.from_numpy(Q).cuda(), k)
+    np.testing.assert_array_equal(rows, rows2.cpu().numpy())
+    np.testing.assert_array_equal(sc, sc2.cpu().numpy())
+
+
+# ---- the reference's FAISSIndex property tests, against the IVF path ------------------------------
+class TestFAISSIndexReferenceProperties:
+    EMBED_DIM = 32
+    N_ITEMS = 500
+
+    @pytest.fixture
+    def built_index(self):
+        from recommendit_amd import FAISSIndex
+        np.random.seed(123)
+        embeddings = np.random.randn(self.N_ITEMS, self.EMBED_DIM).astype(np.float32)
+        embeddings = embeddings / np.linalg.norm(embeddings, axis=1, keepdims=True)
+        item_ids = list(range(1, self.N_ITEMS + 1))
+        index = FAISSIndex(embed_dim=self.EMBED_DIM, n_lists=10, n_probe=5)
+        index.build_ivf_index(embeddings, item_ids)
+        return index, embeddings, item_ids
+
+    def test_index_built(self, built_index):
+        index, _, _ = built_index
+        assert index.index is not None and index.index.ntotal == self.N_ITEMS and index.index.is_ivf
+
+    def test_search_returns_k_results_and_types(self, built_index):
+        index, _, _ = built_index
+        query = np.random.randn(self.EMBED_DIM).astype(np.float32)
+        distances, retrieved_ids = index.search(query, k=20)
+        assert len(distances) == 20 and len(retrieved_ids) == 20
+        assert distances.dtype in [np.float32, np.float64]
+        assert all(isinstance(i, (int, np.integer)) for i in retrieved_ids)
+        assert (np.diff(distances) <= 0.01).all()
+
+    def test_nearest_neighbor_is_self(self, built_index):
+        index, embeddings, item_ids = built_index
+        _, retrieved_ids = index.search(embeddings[42].copy(), k=5)
+        assert item_ids[42] == retrieved_ids[0]
+
+    def test_search_k_capped_and_short_results(self, built_index):
+        index, _, _ = built_index
+        query = np.random.randn(self.EMBED_DIM).astype(np.float32)
+        d, ids = index.search(query, k=10000)
+        assert 0 < len(ids) <= self.N_ITEMS and len(d) == len(ids)   # nprobe*N/nlist < k => fewer than k
+        sc, bid = index.batch_search(query[None], k=10000)
+        assert bid.shape == (1, self.N_ITEMS) and (bid[0, len(ids):] == -1).all()
+        assert list(bid[0, :len(ids)]) == list(ids)
+
+    def test_save_and_load(self, built_index):
+        from recommendit_amd import FAISSIndex
+        index, embeddings, _ = built_index
+        with tempfile.TemporaryDirectory() as tmpdir:
+            path = str(Path(tmpdir) / "faiss.index")
+            index.save(path)
+            assert Path(path).exists() and Path(path).with_suffix(".meta.pkl").exists()
+            loaded = FAISSIndex.load(path)
+            assert loaded.index.ntotal == self.N_ITEMS and loaded.embed_dim == self.EMBED_DIM
+            d1, ids1 = index.search(embeddings[0].copy(), k=10)
+            d2, ids2 = loaded.search(embeddings[0].copy(), k=10)
+            assert list(ids1) == list(ids2)
+            np.testing.assert_array_equal(d1, d2)
+        with pytest.raises(FileNotFoundError):
+            FAISSIndex.load("/nonexistent/faiss.index")
+
+    def test_stats_and_nprobe(self, built_index):
+        index, _, _ = built_index
+        s = index.stats()
+        assert s["n_vectors"] == self.N_ITEMS and s["embed_dim"] == self.EMBED_DIM and s["metric"] == "inner_product"
+        index.set_n_probe(3)
+        assert index.index.nprobe == 3 and index.n_probe == 3
+
+    def test_unnormalized_query_handled(self, built_index):
+        index, _, _ = built_index
+        q = np.random.randn(self.EMBED_DIM).astype(np.float32) * 100
+        _, ids1 = index.search(q, k=5)
+        _, ids2 = index.search(q / np.linalg.norm(q), k=5)
+        assert list(ids1) == list(ids2)
+
+    def test_errors(self):
+        from recommendit_amd import FAISSIndex
+        with pytest.raises(RuntimeError, match="Index not built"):
+            FAISSIndex(embed_dim=32).search(np.zeros(32, np.float32))
+        with pytest.raises(AssertionError):
+            FAISSIndex(embed_dim=32).build_ivf_index(np.zeros((4, 32), np.float64), [1, 2, 3, 4])
+        with pytest.raises(AssertionError):
+            FAISSIndex(embed_dim=32).build_ivf_index(np.zeros((4, 16), np.float32), [1, 2, 3, 4])
+
+
+def test_ivf_full_probe_equals_exact_and_recall():
+    rng = np.random.RandomState(8)
+    N, d, nq, k = 20000, 64, 50, 100
+    X, Q = fx.unit_rows(rng, N, d), fx.unit_rows(rng, nq, d)
+    from recommendit_amd import FAISSIndex
+    ivf = FAISSIndex(embed_dim=d, n_lists=50, n_probe=50)
+    ivf.build_ivf_index(X, list(range(N)))
+    sc, rows = ivf.batch_search(Q, k=k)
+    _check_topk(sc, rows, Q, X, k)                       # nprobe == nlist  =>  exact
+    ivf.set_n_probe(10)
+    sc10, rows10 = ivf.batch_search(Q, k=k)
+    ref_sc, ref_rows = R.topk_ip_exact(Q, X, k)
+    recall = np.mean([len(set(rows10[q]) & set(ref_rows[q])) / k for q in range(nq)])
+    assert recall > 0.5, recall
+    # everything returned is a true inner product of a real row
+    valid = rows10 >= 0
+    S = Q.astype(np.float64) @ X.astype(np.float64).T
+    np.testing.assert_allclose(sc10[valid], np.take_along_axis(S, np.where(valid, rows10, 0), 1)[valid], atol=TOL)

@@ -1,0 +1,243 @@
+"""GPU parity: HIP towers / losses / backward against the golden vectors captured from the
+reference (tests/golden, oracle/make_golden.py) and against the NumPy oracle.
+
+Tolerances (fp32 path, exact-f32 MFMA fmaf chains vs torch-CPU MKL summation order):
+  tower outputs (unit-norm rows)  atol 2e-6
+  gradients                       rtol 2e-4 + small atol
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fixtures as fx
+from oracle import two_tower_np as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(nu, ni, d, H, seed, dropout=0.0):
+    from recommendit_amd import TwoTowerModel
+    sd = fx.make_state(nu, ni, d, H, seed)
+    m = TwoTowerModel(nu, ni, embed_dim=d, hidden_dim=H, dropout=dropout)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    return m, sd
+
+
+def _params(sd, tower):
+    return O.TowerParams(sd[f"{tower}.embedding.weight"], sd[f"{tower}.mlp.0.weight"], sd[f"{tower}.mlp.0.bias"],
+                         sd[f"{tower}.mlp.3.weight"], sd[f"{tower}.mlp.3.bias"])
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def t(x):
+    return torch.from_numpy(np.asarray(x)).to(dev())
+
+
+def test_library_targets_this_gpu():
+    import ctypes
+    from recommendit_amd import _lib
+    buf = ctypes.create_string_buffer(64)
+    _lib.check(_lib.lib().rihip_device_arch(buf, 64))
+    assert buf.value.decode().startswith("gfx950"), buf.value
+
+
+@pytest.mark.parametrize("tag", ["small", "ml1m", "d128"])
+def test_g1_tower_forward_golden(golden_dir, tag):
+    g = np.load(golden_dir / "g1_tower_forward.npz")
+    nu, ni, d, H, seed = (int(x) for x in g[f"{tag}_cfg"])
+    m, sd = _model(nu, ni, d, H, seed)
+    m.eval()
+    for B in (1, 16, 256):
+        u, p, gp, n, gn = fx.make_batch(nu, ni, B, seed=100 + B)
+        with torch.no_grad():
+            U = m.user_tower(t(u)).cpu().numpy()
+            P = m.item_tower(t(p), t(gp)).cpu().numpy()
+        np.testing.assert_allclose(U, g[f"{tag}_B{B}_U"], atol=2e-6, rtol=0)
+        np.testing.assert_allclose(P, g[f"{tag}_B{B}_P"], atol=2e-6, rtol=0)
+
+
+@pytest.mark.parametrize("cfg", [(100, 200, 32, 64), (100, 200, 64, 128), (50, 60, 128, 128), (50, 60, 64, 64),
+                                 (50, 60, 32, 128)])
+@pytest.mark.parametrize("B", [1, 63, 64, 65, 1000])
+def test_tower_forward_vs_oracle_ragged(cfg, B):
+    nu, ni, d, H = cfg
+    m, sd = _model(nu, ni, d, H, seed=77)
+    m.eval()
+    u, p, gp, n, gn = fx.make_batch(nu, ni, B, seed=B)
+    with torch.no_grad():
+        U = m.user_tower(t(u)).cpu().numpy()
+        P = m.item_tower(t(p), t(gp)).cpu().numpy()
+    Uo, _ = O.tower_forward(_params(sd, "user_tower"), u)
+    Po, _ = O.tower_forward(_params(sd, "item_tower"), p, gp)
+    np.testing.assert_allclose(U, Uo, atol=2e-6, rtol=0)
+    np.testing.assert_allclose(P, Po, atol=2e-6, rtol=0)
+
+
+def test_tower_forward_bitwise_reproducible_and_cpu_inputs():
+    m, sd = _model(100, 200, 64, 128, seed=5)
+    m.eval()
+    u, p, gp, _, _ = fx.make_batch(100, 200, 300, seed=1)
+    with torch.no_grad():
+        a = m.item_tower(t(p), t(gp))
+        b = m.item_tower(t(p), t(gp))
+        c = m.item_tower(torch.from_numpy(p), torch.from_numpy(gp))  # CPU inputs -> CPU output
+    assert torch.equal(a, b)
+    assert c.device.type == "cpu" and torch.equal(a.cpu(), c)
+    with pytest.raises(IndexError):
+        m.user_tower(torch.tensor([1, 101]))
+
+
+@pytest.mark.parametrize("tag", ["small", "mid"])
+def test_g2_bpr_grads_golden(golden_dir, tag):
+    g = np.load(golden_dir / "g2_bpr_grads.npz")
+    nu, ni, d, H, seed, B = (int(x) for x in g[f"{tag}_cfg"])
+    m, sd = _model(nu, ni, d, H, seed)
+    m.train()
+    u, p, gp, n, gn = fx.make_batch(nu, ni, B, seed=200 + B)
+    U = m.user_tower(t(u)); P = m.item_tower(t(p), t(gp)); N = m.item_tower(t(n), t(gn))
+    U.retain_grad(); P.retain_grad(); N.retain_grad()
+    loss = m.bpr_loss(U, P, N)
+    loss.backward()
+    assert abs(loss.item() - float(g[f"{tag}_loss"])) < 2e-6
+    tol = dict(atol=3e-7, rtol=3e-4)
+    np.testing.assert_allclose(U.grad.cpu().numpy(), g[f"{tag}_dU"], **tol)
+    np.testing.assert_allclose(P.grad.cpu().numpy(), g[f"{tag}_dP"], **tol)
+    np.testing.assert_allclose(N.grad.cpu().numpy(), g[f"{tag}_dN"], **tol)
+    for k, prm in m.named_parameters():
+        np.testing.assert_allclose(prm.grad.cpu().numpy(), g[f"{tag}_grad_{k}"], err_msg=k, **tol)
+
+
+@pytest.mark.parametrize("cfg", [(100, 200, 32, 64, 200), (100, 200, 64, 128, 129), (50, 60, 128, 128, 70),
+                                 (50, 60, 64, 64, 64), (50, 60, 32, 128, 5)])
+def test_backward_vs_oracle_with_dropout_mask(cfg):
+    """train-mode dropout: the kernel's counter-based mask is reproduced bit-for-bit by the oracle."""
+    nu, ni, d, H, B = cfg
+    p_drop = 0.25
+    m, sd = _model(nu, ni, d, H, seed=9, dropout=p_drop)
+    m.train()
+    u, p, gp, n, gn = fx.make_batch(nu, ni, B, seed=B + 3)
+    torch.manual_seed(1234)
+    seeds = [int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item()) for _ in range(3)]
+    torch.manual_seed(1234)
+    U = m.user_tower(t(u)); P = m.item_tower(t(p), t(gp)); N = m.item_tower(t(n), t(gn))
+    loss = m.bpr_loss(U, P, N)
+    loss.backward()
+    pu, pi = _params(sd, "user_tower"), _params(sd, "item_tower")
+    ku, kp, kn = (O.dropout_keep_mask(s, 0, B, H, p_drop) for s in seeds)
+    Uo, cu = O.tower_forward(pu, u, None, ku, p_drop)
+    Po, cp = O.tower_forward(pi, p, gp, kp, p_drop)
+    No, cn = O.tower_forward(pi, n, gn, kn, p_drop)
+    np.testing.assert_allclose(U.detach().cpu().numpy(), Uo, atol=2e-6)
+    np.testing.assert_allclose(N.detach().cpu().numpy(), No, atol=2e-6)
+    lo, dU, dP, dN = O.bpr_loss(Uo, Po, No)
+    assert abs(loss.item() - float(lo)) < 2e-6
+    bu = O.tower_backward(pu, cu, dU); bp = O.tower_backward(pi, cp, dP); bn = O.tower_backward(pi, cn, dN)
+    tol = dict(atol=3e-7, rtol=3e-4)
+    G = {k: v.grad.cpu().numpy() for k, v in m.named_parameters()}
+    np.testing.assert_allclose(G["user_tower.embedding.weight"], O.embedding_scatter_add(nu + 1, u, bu[0]), **tol)
+    np.testing.assert_allclose(G["item_tower.embedding.weight"],
+                               O.embedding_scatter_add(ni + 1, p, bp[0]) + O.embedding_scatter_add(ni + 1, n, bn[0]), **tol)
+    np.testing.assert_allclose(G["user_tower.mlp.0.weight"], bu[1], **tol)
+    np.testing.assert_allclose(G["user_tower.mlp.0.bias"], bu[2], **tol)
+    np.testing.assert_allclose(G["user_tower.mlp.3.weight"], bu[3], **tol)
+    np.testing.assert_allclose(G["user_tower.mlp.3.bias"], bu[4], **tol)
+    np.testing.assert_allclose(G["item_tower.mlp.0.weight"], bp[1] + bn[1], **tol)
+    np.testing.assert_allclose(G["item_tower.mlp.0.bias"], bp[2] + bn[2], **tol)
+    np.testing.assert_allclose(G["item_tower.mlp.3.weight"], bp[3] + bn[3], **tol)
+    np.testing.assert_allclose(G["item_tower.mlp.3.bias"], bp[4] + bn[4], **tol)
+
+
+@pytest.mark.parametrize("B", [2, 16, 256, 96])
+def test_g3_inbatch_golden(golden_dir, B):
+    from recommendit_amd import TwoTowerModel
+    g = np.load(golden_dir / "g3_inbatch.npz")
+    m = TwoTowerModel(4, 4, 32, 64)
+    U = t(g[f"B{B}_U"]).clone().requires_grad_(True)
+    I = t(g[f"B{B}_I"]).clone().requires_grad_(True)
+    loss = m.in_batch_bpr_loss(U, I)
+    loss.backward()
+    assert abs(loss.item() - float(g[f"B{B}_loss"])) < 3e-6
+    np.testing.assert_allclose(U.grad.cpu().numpy(), g[f"B{B}_dU"], atol=3e-8, rtol=3e-4)
+    np.testing.assert_allclose(I.grad.cpu().numpy(), g[f"B{B}_dI"], atol=3e-8, rtol=3e-4)
+
+
+@pytest.mark.parametrize("B,d", [(33, 32), (130, 64), (500, 128), (1024, 64)])
+def test_inbatch_vs_oracle_ragged_and_reproducible(B, d):
+    from recommendit_amd.two_tower import inbatch_loss_and_grads
+    rng = np.random.RandomState(B)
+    U, I = fx.unit_rows(rng, B, d), fx.unit_rows(rng, B, d)
+    l1, dU1, dI1 = inbatch_loss_and_grads(t(U), t(I))
+    l2, dU2, dI2 = inbatch_loss_and_grads(t(U), t(I))
+    assert torch.equal(dU1, dU2) and torch.equal(dI1, dI2) and torch.equal(l1, l2)
+    lo, dUo, dIo = O.in_batch_bpr_loss(U, I)
+    assert abs(l1.item() - float(lo)) < 3e-6
+    np.testing.assert_allclose(dU1.cpu().numpy(), dUo, atol=3e-9, rtol=3e-4)
+    np.testing.assert_allclose(dI1.cpu().numpy(), dIo, atol=3e-9, rtol=3e-4)
+
+
+def test_inbatch_full_size_properties():
+    """cfg2 size (B=8192, d=64): size-independent properties instead of the O(B^2) oracle:
+    sum_i dU_i . u_i + ... identities: d loss/d(scale) -- here: gradient of a loss that only depends on
+    score differences is orthogonal to a uniform shift of all item vectors along any user direction, and
+    sum over rows of G is zero => sum_j dI_j == sum_i G^T 1 ... we check  sum(dI) == sum_i (sum_j G_ij) u_i == 0."""
+    from recommendit_amd.two_tower import inbatch_loss_and_grads
+    rng = np.random.RandomState(0)
+    B, d = 8192, 64
+    U, I = fx.unit_rows(rng, B, d), fx.unit_rows(rng, B, d)
+    loss, dU, dI = inbatch_loss_and_grads(t(U), t(I))
+    assert 0.3 < loss.item() < 1.2
+    # rows of G sum to zero  =>  dU_i . 1-shift: sum_j G_ij = 0  => sum_i dI_i = G^T U summed over j = U^T (G 1) = 0
+    assert dI.sum(0).abs().max().item() < 1e-6
+    # subset check against the oracle on the first 64 users (needs all items): rectangular oracle
+    lo, dUo, _ = O.in_batch_bpr_loss(U[:64], I, owner_offset=0, n_global=B)
+    np.testing.assert_allclose(dU[:64].cpu().numpy(), dUo, atol=1e-10, rtol=5e-4)
+
+
+def test_g4_train50_golden_with_stock_adam(golden_dir):
+    """Drop-in check: stock torch.optim.Adam + clip_grad_norm_ + CosineAnnealingLR drive the HIP model
+    exactly like the reference loop (train_embeddings.py:183-197)."""
+    g = np.load(golden_dir / "g4_train50.npz")
+    nu, ni, d, H, seed, B = (int(x) for x in g["cfg"])
+    m, sd = _model(nu, ni, d, H, seed)
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2, weight_decay=1e-5)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=2)
+    for step in range(50):
+        u, p, gp, n, gn = fx.make_batch(nu, ni, B, seed=4000 + step, boundary=False)
+        U = m.user_tower(t(u)); P = m.item_tower(t(p), t(gp)); N = m.item_tower(t(n), t(gn))
+        loss = m.bpr_loss(U, P, N)
+        opt.zero_grad(); loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=1.0)
+        opt.step()
+        assert abs(loss.item() - g["losses"][step]) < 5e-5, step
+        if step == 24:
+            sched.step()
+    for k, prm in m.named_parameters():
+        np.testing.assert_allclose(prm.detach().cpu().numpy(), g[f"final_{k}"], atol=2e-4, rtol=0, err_msg=k)
+
+
+def test_g5_g6_inference_and_reference_checkpoint(golden_dir, tmp_path):
+    from recommendit_amd import TwoTowerModel
+    g = np.load(golden_dir / "g5_inference.npz")
+    nu, ni, d, H, seed = (int(x) for x in g["cfg"])
+    m, sd = _model(nu, ni, d, H, seed)
+    E = m.get_item_embeddings(list(range(1, 1001)), g["genres"])
+    np.testing.assert_allclose(E, g["item_embs"], atol=2e-6)
+    np.testing.assert_allclose(m.get_user_embedding(7), g["user7"], atol=2e-6)
+    np.testing.assert_allclose(m.get_user_embedding(100), g["user100"], atol=2e-6)
+    # a checkpoint written by the reference's save() loads and reproduces its outputs
+    ref = TwoTowerModel.load(str(golden_dir / "g6_reference_checkpoint.pt"))
+    exp = np.load(golden_dir / "g6_expected.npz")["U"]
+    with torch.no_grad():
+        got = ref.user_tower(torch.tensor([1, 2, 20])).numpy()
+    np.testing.assert_allclose(got, exp, atol=2e-6)
+    assert ref._item_id_to_idx == {1: 0, 2: 1, 3: 2}
+    # own save/load round trip with a non-default hidden_dim (the reference cannot do this)
+    m.precompute_item_embeddings([1, 2, 3], np.zeros((3, 18), np.float32))
+    m.save(str(tmp_path / "tt.pt"))
+    m2 = TwoTowerModel.load(str(tmp_path / "tt.pt"))
+    assert (m2.n_users, m2.n_items, m2.embed_dim, m2.hidden_dim) == (nu, ni, d, H)
+    np.testing.assert_allclose(m2.get_user_embedding(7), g["user7"], atol=2e-6)
