@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""bench.py -- BPR pairs/sec (+ top-500 IP queries/sec) of the MI355X hot path.
+
+    python bench.py --gpus N --steps K --warmup W           (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json north_star: "synthetic 10M-user x 1M-item d=128"): one step = one pass of
+the Two-Tower BPR training path (towers fwd -> in-batch-negative BPR -> towers bwd -> global
+clip-norm -> Adam on MLPs + row-sparse Adam on touched embedding rows) over a GLOBAL batch of 65 536
+synthetic pairs with global in-batch negatives.  Strong scaling: tables and global batch are fixed;
+N ranks shard the user rows and the batch (8 192 pairs per rank at N=8, the cfg-4 shape), the item
+table is replicated, in-batch negatives stay global through RCCL all-gathers of the tower outputs.
+Inputs (ids, genres, tables) are resident in HBM before the timed region.
+
+Extra objects on the JSON line: `roofline` (dominant kernel = in-batch sweep, exact-f32 MFMA bound),
+`cpu_baseline` (NumPy oracle on host cores, bounded sample), `secondary` (sampled-negative pairs/s --
+the mode the reference actually trains in -- and top-500 brute-force IP queries/s with its own roofline).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+N_USERS, N_ITEMS, D, H = 10_000_000, 1_000_000, 128, 128
+GLOBAL_BATCH = 65536
+K_TOP = 500
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(*a, file=sys.stderr, flush=True)
+
+
+def make_model(n_users_local, n_items, d, hidden, seed):
+    from recommendit_amd import TwoTowerModel
+    torch.manual_seed(seed)
+    m = TwoTowerModel(n_users_local, n_items, embed_dim=d, hidden_dim=hidden, dropout=0.1)
+    m.train()
+    return m
+
+
+def zipf_ids(n, n_items, a, gen, device):
+    """item ids ~ Zipf(a) over [1, n_items] by inverse-CDF of the continuous approximation (popularity skew
+    stresses the row-gradient grouping)."""
+    u = torch.rand((n,), device=device, generator=gen, dtype=torch.float64)
+    # P(X <= x) ~ (x^(1-a) - 1) / (N^(1-a) - 1)
+    x = (1.0 + u * (float(n_items) ** (1.0 - a) - 1.0)) ** (1.0 / (1.0 - a))
+    return x.floor().clamp_(1, n_items).to(torch.int64)
+
+
+def make_batches(n, B, n_users_local, n_items, device, seed, sampled):
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    out = []
+    for _ in range(n):
+        u = torch.randint(1, n_users_local + 1, (B,), device=device, generator=gen)
+        items = zipf_ids(B * (2 if sampled else 1), n_items, 1.05, gen, device)
+        genres = (torch.rand((items.numel(), 18), device=device, generator=gen) < 0.1).float()
+        out.append((u, items, genres))
+    return out
+
+
+def timed(fn, n, world):
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n):
+        fn(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def cpu_baseline_inbatch(seconds_budget=25.0):
+    """NumPy oracle on the host cores, bounded sample of the SAME workload: a block of 512 users (and their 512
+    positive items) of one global step against all 65 536 in-batch items: towers fwd+bwd for the block's rows +
+    in-batch loss/gradients (the rectangular form of two_tower.py:132-160).  Same work per pair as the GPU run."""
+    from oracle import fixtures as fx
+    from oracle import two_tower_np as O
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    blk, G = 512, GLOBAL_BATCH
+    sd = fx.make_state(4096, 4096, D, H, seed=1)
+    rng = np.random.RandomState(0)
+    I_all = fx.unit_rows(rng, G, D)
+    pu = O.TowerParams(sd["user_tower.embedding.weight"], sd["user_tower.mlp.0.weight"], sd["user_tower.mlp.0.bias"],
+                       sd["user_tower.mlp.3.weight"], sd["user_tower.mlp.3.bias"])
+    pi = O.TowerParams(sd["item_tower.embedding.weight"], sd["item_tower.mlp.0.weight"], sd["item_tower.mlp.0.bias"],
+                       sd["item_tower.mlp.3.weight"], sd["item_tower.mlp.3.bias"])
+    n_done, t0 = 0, time.perf_counter()
+    while True:
+        u, p, gp, _, _ = fx.make_batch(4096, 4096, blk, seed=n_done, boundary=False)
+        U, cu = O.tower_forward(pu, u)
+        P, cp = O.tower_forward(pi, p, gp)
+        I_all[:blk] = P
+        _, dU, dI = O.in_batch_bpr_loss(U, I_all, owner_offset=0, n_global=G)
+        O.tower_backward(pu, cu, dU)
+        O.tower_backward(pi, cp, dI[:blk])
+        n_done += blk
+        if time.perf_counter() - t0 > seconds_budget or n_done >= 8 * blk:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n_done / dt, "unit": "pairs/s", "cores": int(cores), "kind": "port",
+            "sample": f"{n_done} pairs = {n_done // blk} blocks of {blk} users x all {G} in-batch items of one step "
+                      f"(towers fwd+bwd + in-batch loss/grads, NumPy oracle, float64 score block), {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--global-batch", type=int, default=GLOBAL_BATCH)
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--users", type=int, default=N_USERS)
+    ap.add_argument("--items", type=int, default=N_ITEMS)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from recommendit_amd.trainer import HipBPRTrainer
+    G = args.global_batch
+    assert G % world == 0
+    B = G // world
+    n_users_local = args.users // world
+    K, W = args.steps, args.warmup
+
+    # ------------------------------------------------------------------ headline: in-batch BPR
+    model = make_model(n_users_local, args.items, D, H, seed=1234)  # same seed: replicated item table + MLPs
+    if world > 1:  # user shards differ per rank
+        g = torch.Generator(device=dev); g.manual_seed(100 + rank)
+        model.user_tower.embedding.weight.data.uniform_(-0.0007, 0.0007, generator=g)
+    tr = HipBPRTrainer(model, B, lr=1e-3, weight_decay=1e-5, loss_mode="inbatch", table_opt="sparse", seed=rank,
+                       process_group=None)
+    batches = make_batches(W + K, B, n_users_local, args.items, dev, seed=7 + rank, sampled=False)
+    ev = []
+
+    def step(i):
+        u, it, g = batches[i % len(batches)]
+        tr.step(u, it, g)
+
+    for i in range(W):
+        step(i)
+    # per-launch duration of the dominant kernel, measured on the launch stream inside the timed region
+    tr.sweep_events = ev
+    dt = timed(lambda i: step(W + i), K, world)
+    tr.sweep_events = None
+    loss = float(tr.loss.item())
+    pairs_per_s = G * K / dt
+    sweep_ms = [a.elapsed_time(b) for a, b in ev]
+    n_launch = len(sweep_ms)                          # one bracket per launch (user-mode and item-mode sweeps)
+    t_launch = sum(sweep_ms) / 1e3 / max(n_launch, 1)
+    flop_launch = 3.0 * B * G * D                     # algorithmic: 6*B_neg*d per pair / 2 launches
+    achieved = flop_launch / t_launch / 1e12 if t_launch > 0 else 0.0
+    traffic = None
+    tf = ROOT / "profiles" / "traffic.json"
+    if tf.exists():
+        try:
+            traffic = json.loads(tf.read_text()).get(f"inbatch_sweep_n{world}")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "mfma", "kernel": "inbatch_sweep_kernel<128>", "achieved": achieved,
+                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                "traffic": traffic, "launch_ms": t_launch * 1e3, "algorithmic_flop_per_launch": flop_launch,
+                "executed_flop_per_launch": 4.0 * B * G * D}
+    log(f"[bench] in-batch: {pairs_per_s:,.0f} pairs/s, {dt / K * 1e3:.2f} ms/step, loss {loss:.4f}, "
+        f"sweep {t_launch * 1e3:.3f} ms/launch = {achieved:.1f} TFLOP/s algorithmic")
+    del tr, model, batches
+    torch.cuda.empty_cache()
+
+    secondary = {}
+    if not args.no_secondary:
+        # -------------------------------------------------------------- sampled-negative BPR (reference's mode)
+        Bs = 65536 // world
+        model = make_model(n_users_local, args.items, D, H, seed=1234)
+        tr = HipBPRTrainer(model, Bs, loss_mode="sampled", table_opt="sparse", seed=rank)
+        batches = make_batches(W + K, Bs, n_users_local, args.items, dev, seed=9 + rank, sampled=True)
+        for i in range(W):
+            tr.step(*batches[i])
+        dts = timed(lambda i: tr.step(*batches[(W + i) % len(batches)]), K, world)
+        sp = Bs * world * K / dts
+        # HBM roofline of the sparse formulation: 9 384 B/pair at d=128; MFMA: 617 472 FLOP/pair
+        secondary["sampled_bpr"] = {"metric": "bpr_pairs_per_sec_sampled_negative", "value": sp, "unit": "pairs/s",
+                                    "ms_per_step": dts / K * 1e3, "global_batch": Bs * world,
+                                    "frac_of_f32_mfma_roofline": sp * 617472 / (PEAK_F32_MFMA_TFLOPS * 1e12 * world),
+                                    "frac_of_hbm_roofline": sp * 9384 / (8.0e12 * world)}
+        log(f"[bench] sampled: {sp:,.0f} pairs/s, {dts / K * 1e3:.2f} ms/step")
+        # -------------------------------------------------------------- top-500 brute-force IP retrieval
+        from recommendit_amd import FAISSIndex
+        g = torch.Generator(device=dev); g.manual_seed(1)
+        X = torch.randn((args.items, D), device=dev, generator=g)
+        X = (X / X.norm(dim=1, keepdim=True)).contiguous()
+        idx = FAISSIndex(embed_dim=D, exact=True)
+        idx.build_from_device(X, np.arange(1, args.items + 1))
+        nq = 4096
+        model.eval()
+        qs = []
+        for i in range(2):
+            uid = torch.randint(1, n_users_local + 1, (nq,), device=dev, generator=g)
+            qs.append(model.get_user_embeddings(uid, as_tensor=True))   # queries = user-tower outputs (unit norm)
+        for i in range(1):
+            idx.batch_search_device(qs[0], k=K_TOP, normalized=True)
+        Kq = max(2, K // 2)
+        dtq = timed(lambda i: idx.batch_search_device(qs[i % 2], k=K_TOP, normalized=True), Kq, world)
+        qps = nq * world * Kq / dtq
+        flop_q = 2.0 * args.items * D
+        secondary["retrieval"] = {"metric": "top500_ip_queries_per_sec", "value": qps, "unit": "queries/s",
+                                  "ms_per_batch": dtq / Kq * 1e3, "queries_per_batch": nq * world, "k": K_TOP,
+                                  "corpus": f"{args.items}x{D} f32, exact brute force",
+                                  "roofline": {"bound": "mfma", "achieved": qps * flop_q / 1e12 / world,
+                                               "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                               "frac": qps * flop_q / 1e12 / world / PEAK_F32_MFMA_TFLOPS}}
+        log(f"[bench] retrieval: {qps:,.0f} q/s ({dtq / Kq * 1e3:.2f} ms per {nq} queries)")
+        del tr, model, idx, X
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_inbatch()
+        log(f"[bench] cpu oracle: {cpu['value']:.1f} pairs/s on {cpu['cores']} threads")
+
+    if rank == 0:
+        line = {
+            "metric": "bpr_pairs_per_sec", "value": pairs_per_s, "unit": "pairs/s", "n_gpus": world, "steps": K,
+            "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"synthetic {args.users // 1_000_000}M users x {args.items // 1_000_000}M items, "
+                                   f"d={D}, hidden={H}: Two-Tower BPR step, global batch {G} with global in-batch "
+                                   f"negatives, row-sparse Adam, random-init weights",
+                       "global_batch": G, "per_gpu_batch": B, "embed_dim": D, "loss_mode": "inbatch",
+                       "parallelism": f"user-row-shard x{world}, item table replicated"},
+            "final_loss": loss, "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,38 @@
+"""Collectives used by the multi-GPU training step (one process per GPU, torch.distributed).
+
+On MI355X the backend is "nccl" (= RCCL over xGMI) and tensors stay on the device.  With the
+"gloo" backend (CPU rehearsal / several ranks sharing one GPU in tests) device tensors are staged
+through host memory so the very same call sequence runs."""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def _staged(t: torch.Tensor, group) -> bool:
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_gather_into(out: torch.Tensor, inp: torch.Tensor, group=None) -> None:
+    """out[rank*n:(rank+1)*n] = inp of that rank (row-major concatenation over ranks)."""
+    if _staged(inp, group):
+        W = dist.get_world_size(group)
+        parts = [torch.empty(inp.shape, dtype=inp.dtype) for _ in range(W)]
+        dist.all_gather(parts, inp.detach().cpu().contiguous(), group=group)
+        out.copy_(torch.cat(parts, 0).to(out.device))
+    elif inp.is_cuda:
+        dist.all_gather_into_tensor(out, inp.contiguous(), group=group)
+    else:
+        W = dist.get_world_size(group)
+        parts = [torch.empty_like(inp) for _ in range(W)]
+        dist.all_gather(parts, inp.contiguous(), group=group)
+        out.copy_(torch.cat(parts, 0))
+
+
+def all_reduce_sum_(t: torch.Tensor, group=None) -> None:
+    if _staged(t, group):
+        c = t.detach().cpu()
+        dist.all_reduce(c, group=group)
+        t.copy_(c.to(t.device))
+    else:
+        dist.all_reduce(t, group=group)

@@ -1,0 +1,79 @@
+"""Seeded synthetic data of the shapes BASELINE.json names (there is no MovieLens offline).
+
+ml1m_like(): a MovieLens-1M-*shaped* ratings table (6 040 users, 3 952-wide item-id space with
+3 883 catalogue items, ~1.0 M ratings, ML-1M rating histogram, per-user increasing timestamps,
+18-genre multi-hot) drawn from a low-rank latent model so that ranking quality is learnable.
+File formats follow the reference loader (src/features/feature_engineering.py:43-65)."""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Dict, Tuple
+
+import numpy as np
+import pandas as pd
+
+GENRES = ["Action", "Adventure", "Animation", "Children's", "Comedy", "Crime", "Documentary", "Drama", "Fantasy",
+          "Film-Noir", "Horror", "Musical", "Mystery", "Romance", "Sci-Fi", "Thriller", "War", "Western"]
+N_GENRES = len(GENRES)
+
+
+def ml1m_like(n_users: int = 6040, n_item_ids: int = 3952, n_catalog: int = 3883, n_ratings: int = 1_000_209,
+              rank: int = 8, seed: int = 0) -> Tuple[pd.DataFrame, pd.DataFrame, np.ndarray]:
+    """Returns (ratings_df[user_id,item_id,rating,timestamp], movies_df[item_id,title,genres], genre_matrix
+    [n_item_ids+1,18] f32).  Deterministic for a given seed."""
+    rng = np.random.RandomState(seed)
+    catalog = np.sort(rng.choice(np.arange(1, n_item_ids + 1), size=n_catalog, replace=False))
+    zu = rng.randn(n_users + 1, rank).astype(np.float32)
+    zi = rng.randn(n_item_ids + 1, rank).astype(np.float32)
+    pop = rng.zipf(1.3, size=n_catalog).astype(np.float64)
+    pop = pop / pop.sum()
+    # per-user activity ~ log-normal, at least 20 ratings like ML-1M
+    act = np.maximum(20, rng.lognormal(mean=4.6, sigma=0.9, size=n_users)).astype(np.float64)
+    act = np.minimum(act, n_catalog * 0.6)
+    act = act * (n_ratings / act.sum())
+    cnt = np.maximum(20, np.round(act).astype(np.int64))
+    users, items = [], []
+    for u in range(1, n_users + 1):
+        c = int(min(cnt[u - 1], n_catalog))
+        # preference-biased choice without replacement: popularity x exp(affinity)
+        aff = zi[catalog] @ zu[u]
+        w = pop * np.exp(0.8 * (aff - aff.max()))
+        w /= w.sum()
+        it = rng.choice(catalog, size=c, replace=False, p=w)
+        users.append(np.full(c, u, dtype=np.int64))
+        items.append(it.astype(np.int64))
+    users = np.concatenate(users)
+    items = np.concatenate(items)
+    score = (zu[users] * zi[items]).sum(1) / np.sqrt(rank) + 0.6 * rng.randn(users.size)
+    # ML-1M histogram {1:5.6%, 2:10.8%, 3:26.1%, 4:34.9%, 5:22.6%} through score quantiles
+    qs = np.quantile(score, [0.056, 0.164, 0.425, 0.774])
+    rating = 1 + (score[:, None] > qs[None, :]).sum(1)
+    # timestamps: increasing within each user in generation order
+    order = np.arange(users.size)
+    ts = 956_703_932 + order * 7
+    ratings = pd.DataFrame({"user_id": users, "item_id": items, "rating": rating.astype(np.int64), "timestamp": ts})
+    gm = np.zeros((n_item_ids + 1, N_GENRES), dtype=np.float32)
+    titles, gstr = [], []
+    for it in catalog:
+        k = rng.randint(1, 4)
+        gs = np.sort(rng.choice(N_GENRES, size=k, replace=False))
+        gm[it, gs] = 1.0
+        titles.append(f"Movie {it} ({1930 + int(it) % 70})")
+        gstr.append("|".join(GENRES[g] for g in gs))
+    movies = pd.DataFrame({"item_id": catalog.astype(np.int64), "title": titles, "genres": gstr})
+    return ratings, movies, gm
+
+
+def write_ml1m_files(out_dir: str, ratings: pd.DataFrame, movies: pd.DataFrame, n_users: int) -> None:
+    """ratings.dat / movies.dat / users.dat in the '::' format the reference loader reads."""
+    p = Path(out_dir)
+    p.mkdir(parents=True, exist_ok=True)
+    with open(p / "ratings.dat", "w", encoding="latin-1") as f:
+        for u, i, r, t in ratings[["user_id", "item_id", "rating", "timestamp"]].itertuples(index=False):
+            f.write(f"{u}::{i}::{r}::{t}\n")
+    with open(p / "movies.dat", "w", encoding="latin-1") as f:
+        for i, t, g in movies[["item_id", "title", "genres"]].itertuples(index=False):
+            f.write(f"{i}::{t}::{g}\n")
+    with open(p / "users.dat", "w", encoding="latin-1") as f:
+        for u in range(1, n_users + 1):
+            f.write(f"{u}::{'MF'[u % 2]}::{[1, 18, 25, 35, 45, 50, 56][u % 7]}::{u % 21}::{10000 + u % 89999}\n")

@@ -1,0 +1,308 @@
+"""Fused BPR training step over the C ABI -- the body of the reference's hot loop
+(src/training/train_embeddings.py:183-192: towers -> bpr_loss -> backward -> clip_grad_norm_
+-> Adam.step) without autograd, without host syncs, with preallocated buffers.
+
+Two optimiser modes for the embedding tables:
+  * ``dense``  -- the reference's exact semantics: dense gradient, every row decays through the
+    coupled L2 term and moves every step.  Used for the ML-1M parity configs.
+  * ``sparse`` -- row-wise Adam on touched rows only (sort ids -> segment-reduce -> fused row
+    update).  The only feasible mode at 10M/100M rows; deviation from the reference: untouched rows
+    neither decay nor move.  Throughput configs run this.
+MLP parameters are always dense (one flat buffer: one grad-norm pass + one Adam launch).
+
+Two loss modes: ``sampled`` (one explicit negative per positive -- what the reference trains
+with) and ``inbatch`` (TwoTowerModel.in_batch_bpr_loss, never called by the reference trainer).
+
+Multi-GPU (one process per GPU, torch.distributed/RCCL): user rows are sharded (each rank trains
+pairs whose user row it owns: zero communication for user rows), the item table is replicated and
+kept identical by all-gathering the per-rank (item id, row-gradient) lists; in-batch negatives are
+global through an all-gather of tower outputs; MLP grads are all-reduced; the clip norm is one
+all-reduced scalar.  See DESIGN.md "Multi-GPU".
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+from .dist_utils import all_gather_into, all_reduce_sum_
+from .two_tower import N_GENRES, TwoTowerModel
+
+_MLP_KEYS = ["user_tower.mlp.0.weight", "user_tower.mlp.0.bias", "user_tower.mlp.3.weight", "user_tower.mlp.3.bias",
+             "item_tower.mlp.0.weight", "item_tower.mlp.0.bias", "item_tower.mlp.3.weight", "item_tower.mlp.3.bias"]
+
+
+class _RowsOpt:
+    """Row-sparse Adam state for one table (ids may repeat; up to max_ids per step)."""
+
+    def __init__(self, table: torch.Tensor, max_ids: int):
+        lib = L.lib()
+        dev = table.device
+        self.table = table
+        self.d = table.shape[1]
+        self.m = torch.zeros_like(table)
+        self.v = torch.zeros_like(table)
+        self.max_ids = max_ids
+        nbytes = lib.rihip_rows_workspace_bytes(max_ids)
+        if nbytes < 0:
+            raise RuntimeError("rihip_rows_workspace_bytes failed")
+        self.ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        self.uniq = torch.empty((max_ids,), dtype=torch.int64, device=dev)
+        self.Gc = torch.empty((max_ids, self.d), dtype=torch.float32, device=dev)
+
+    def group_reduce(self, ids: torch.Tensor, dX: torch.Tensor, part_ptr: int, st: int) -> None:
+        lib = L.lib()
+        B = ids.numel()
+        assert B <= self.max_ids
+        L.check(lib.rihip_rows_group(ids.data_ptr(), B, self.uniq.data_ptr(), self.ws.data_ptr(), self.ws.numel(), st),
+                "rows_group")
+        L.check(lib.rihip_rows_reduce(dX.data_ptr(), B, self.d, self.uniq.data_ptr(), self.ws.data_ptr(),
+                                      self.Gc.data_ptr(), part_ptr, st), "rows_reduce")
+        self._B = B
+
+    def adam(self, lr, b1, b2, eps, wd, step, coef_ptr, st) -> None:
+        L.check(L.lib().rihip_adam_rows(self.table.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                        self.uniq.data_ptr(), self.Gc.data_ptr(), self._B, self.d, self.ws.data_ptr(),
+                                        lr, b1, b2, eps, wd, step, coef_ptr, st), "adam_rows")
+
+
+class _DenseOpt:
+    def __init__(self, table: torch.Tensor):
+        self.table = table
+        self.d = table.shape[1]
+        self.m = torch.zeros_like(table)
+        self.v = torch.zeros_like(table)
+        self.grad = torch.zeros_like(table)
+
+    def scatter(self, ids: torch.Tensor, dX: torch.Tensor, st: int, zero: bool = True) -> None:
+        if zero:
+            self.grad.zero_()
+        L.check(L.lib().rihip_embedding_scatter_add(self.grad.data_ptr(), self.table.shape[0], ids.data_ptr(),
+                                                    dX.data_ptr(), ids.numel(), self.d, st), "embedding_scatter_add")
+
+    def sumsq(self, part_ptr: int, st: int) -> None:
+        L.check(L.lib().rihip_sumsq(self.grad.data_ptr(), self.grad.numel(), part_ptr, st), "sumsq")
+
+    def adam(self, lr, b1, b2, eps, wd, step, coef_ptr, st) -> None:
+        L.check(L.lib().rihip_adam_dense(self.table.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(),
+                                         self.v.data_ptr(), self.table.numel(), lr, b1, b2, eps, wd, step, coef_ptr,
+                                         st), "adam_dense")
+
+
+class HipBPRTrainer:
+    def __init__(self, model: TwoTowerModel, batch_size: int, lr: float = 1e-3, weight_decay: float = 1e-5,
+                 betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = 1.0, loss_mode: str = "sampled",
+                 table_opt: str = "dense", seed: int = 0, process_group=None, user_row_offset: int = 0):
+        assert loss_mode in ("sampled", "inbatch") and table_opt in ("dense", "sparse")
+        self.lib = L.lib()
+        self.model = model
+        self.dev = L.device()
+        self.B = int(batch_size)
+        self.lr, self.wd, self.b1, self.b2, self.eps, self.max_norm = lr, weight_decay, betas[0], betas[1], eps, max_norm
+        self.loss_mode, self.table_opt = loss_mode, table_opt
+        self.step_count = 0
+        self.seed = seed
+        self.sweep_events = None  # bench hook: list collecting (start, end) events around every sweep launch
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
+        self.rank = dist.get_rank(process_group) if self.world > 1 else 0
+        self.user_row_offset = int(user_row_offset)  # global id of local user-table row 0 (sharded tables)
+        d, H = model.embed_dim, model.hidden_dim
+        self.d, self.H = d, H
+        self.p_drop = float(model.user_tower.mlp[2].p)
+
+        # ---- flat MLP parameter / grad / moment buffers; module parameters become views
+        sd = dict(model.named_parameters())
+        sizes = [sd[k].numel() for k in _MLP_KEYS]
+        offs, tot = [], 0
+        for s in sizes:
+            offs.append(tot)
+            tot += (s + 3) // 4 * 4  # keep every tensor 16-byte aligned inside the flat buffer
+        self.flat_p = torch.zeros((tot,), dtype=torch.float32, device=self.dev)
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.flat_m = torch.zeros_like(self.flat_p)
+        self.flat_v = torch.zeros_like(self.flat_p)
+        self.pv: Dict[str, torch.Tensor] = {}
+        self.gv: Dict[str, torch.Tensor] = {}
+        for k, o, s in zip(_MLP_KEYS, offs, sizes):
+            prm = sd[k]
+            view = self.flat_p[o:o + s].view_as(prm)
+            view.copy_(prm.data)
+            prm.data = view
+            self.pv[k] = view
+            self.gv[k] = self.flat_g[o:o + s].view_as(prm)
+        self.utab = model.user_tower.embedding.weight.data
+        self.itab = model.item_tower.embedding.weight.data
+        nI = self.B * (2 if loss_mode == "sampled" else 1)
+        nI_all = nI * (self.world if self.world > 1 else 1)  # replicated item table sees every rank's rows
+        if table_opt == "sparse":
+            self.uopt = _RowsOpt(self.utab, self.B)
+            self.iopt = _RowsOpt(self.itab, nI_all)
+        else:
+            assert self.world == 1, "dense table optimiser is single-GPU (parity mode)"
+            self.uopt = _DenseOpt(self.utab)
+            self.iopt = _DenseOpt(self.itab)
+
+        # ---- per-step buffers
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        B = self.B
+        self.U = torch.empty((B, d), **f32); self.hidU = torch.empty((B, H), **f32); self.denU = torch.empty((B,), **f32)
+        self.I = torch.empty((nI, d), **f32); self.hidI = torch.empty((nI, H), **f32); self.denI = torch.empty((nI,), **f32)
+        self.dU = torch.empty((B, d), **f32); self.dI = torch.empty((nI, d), **f32)
+        self.dXu = torch.empty((B, d), **f32); self.dXi = torch.empty((nI, d), **f32)
+        self.loss = torch.zeros((), **f32)
+        self.coef = torch.ones((1,), **f32); self.gnorm = torch.zeros((1,), **f32)
+        self.err = torch.zeros((1,), dtype=torch.int32, device=self.dev)
+        nws = max(self.lib.rihip_tower_backward_workspace_floats(B, d, H, 0),
+                  self.lib.rihip_tower_backward_workspace_floats(nI, d, H, 1))
+        self.bws = torch.empty((nws,), **f32)
+        self.np_mlp = self.lib.rihip_sumsq_nparts()
+        self.np_rows = self.lib.rihip_rows_nparts() if table_opt == "sparse" else self.np_mlp
+        self.part = torch.zeros((self.np_mlp + 2 * self.np_rows + 8,), dtype=torch.float64, device=self.dev)
+        self.lpart = torch.zeros((max(1024, self.lib.rihip_inbatch_workspace_doubles(B)),), dtype=torch.float64,
+                                 device=self.dev)
+        if loss_mode == "inbatch":
+            self.pos = torch.empty((B,), **f32); self.r = torch.empty((B,), **f32)
+            if self.world > 1:
+                W = self.world
+                self.U_all = torch.empty((W * B, d), **f32); self.I_all = torch.empty((W * B, d), **f32)
+                self.pos_all = torch.empty((W * B,), **f32); self.r_all = torch.empty((W * B,), **f32)
+        if self.world > 1:
+            W = self.world
+            self.iid_all = torch.empty((W * nI,), dtype=torch.int64, device=self.dev)
+            self.dXi_all = torch.empty((W * nI, d), **f32)
+
+    # ------------------------------------------------------------------------------------------
+    def _fwd(self, table, ids, genres, keys, out, hid, den, seed):
+        training = self.model.training and self.p_drop > 0
+        L.check(self.lib.rihip_tower_forward(table.data_ptr(), table.shape[0], ids.data_ptr(), L.ptr(genres),
+                                             ids.numel(), self.d, self.H, self.pv[keys[0]].data_ptr(),
+                                             self.pv[keys[1]].data_ptr(), self.pv[keys[2]].data_ptr(),
+                                             self.pv[keys[3]].data_ptr(), 1 if training else 0, self.p_drop, seed, 0,
+                                             out.data_ptr(), hid.data_ptr(), den.data_ptr(), self.err.data_ptr(),
+                                             self._st), "tower_forward")
+
+    def _bwd(self, table, ids, genres, keys, gout, out, den, hid, dX):
+        scale = 1.0 / (1.0 - self.p_drop) if (self.model.training and self.p_drop > 0) else 1.0
+        L.check(self.lib.rihip_tower_backward(table.data_ptr(), table.shape[0], ids.data_ptr(), L.ptr(genres),
+                                              ids.numel(), self.d, self.H, self.pv[keys[0]].data_ptr(),
+                                              self.pv[keys[2]].data_ptr(), gout.data_ptr(), out.data_ptr(),
+                                              den.data_ptr(), hid.data_ptr(), scale, dX.data_ptr(),
+                                              self.gv[keys[0]].data_ptr(), self.gv[keys[1]].data_ptr(),
+                                              self.gv[keys[2]].data_ptr(), self.gv[keys[3]].data_ptr(), 0,
+                                              self.bws.data_ptr(), self._st), "tower_backward")
+
+    def step(self, user_ids: torch.Tensor, item_ids: torch.Tensor, item_genres: torch.Tensor,
+             lr: Optional[float] = None) -> torch.Tensor:
+        """One optimisation step.  user_ids int64 [B] (LOCAL row ids when tables are sharded);
+        sampled mode: item_ids [2B] = pos || neg, item_genres [2B,18]; inbatch: [B] / [B,18].
+        Returns the loss as a 0-dim device tensor (no host sync)."""
+        lib, B, d = self.lib, self.B, self.d
+        assert user_ids.numel() == B and item_ids.numel() == self.I.shape[0]
+        self._st = st = L.stream_ptr()
+        self.step_count += 1
+        t = self.step_count
+        lr = self.lr if lr is None else lr
+        ukeys, ikeys = _MLP_KEYS[:4], _MLP_KEYS[4:]
+        s0 = (self.seed * 1000003 + t * 2 + self.rank * 7919) & ((1 << 62) - 1)
+        self._fwd(self.utab, user_ids, None, ukeys, self.U, self.hidU, self.denU, s0)
+        self._fwd(self.itab, item_ids, item_genres, ikeys, self.I, self.hidI, self.denI, s0 + 1)
+
+        if self.loss_mode == "sampled":
+            L.check(lib.rihip_bpr_pair_loss(self.U.data_ptr(), self.I.data_ptr(), self.I[B:].data_ptr(), B, d,
+                                            self.loss.data_ptr(), self.dU.data_ptr(), self.dI.data_ptr(),
+                                            self.dI[B:].data_ptr(), self.lpart.data_ptr(), st), "bpr_pair_loss")
+            if self.world > 1:  # mean over the global batch
+                self.dU.div_(self.world); self.dI.div_(self.world)
+                self.loss.div_(self.world)
+                all_reduce_sum_(self.loss, self.pg)
+        else:
+            self._inbatch(st)
+
+        self._bwd(self.utab, user_ids, None, ukeys, self.dU, self.U, self.denU, self.hidU, self.dXu)
+        self._bwd(self.itab, item_ids, item_genres, ikeys, self.dI, self.I, self.denI, self.hidI, self.dXi)
+
+        # ---- gradient exchange (multi-GPU) + global grad norm -> clip coef (device scalar)
+        iid, dXi = item_ids, self.dXi
+        if self.world > 1:
+            all_reduce_sum_(self.flat_g, self.pg)
+            all_gather_into(self.iid_all, item_ids, self.pg)
+            all_gather_into(self.dXi_all, self.dXi, self.pg)
+            iid, dXi = self.iid_all, self.dXi_all
+        pp = self.part.data_ptr()
+        L.check(lib.rihip_sumsq(self.flat_g.data_ptr(), self.flat_g.numel(), pp, st), "sumsq")
+        o1 = self.np_mlp
+        o2 = o1 + self.np_rows
+        if self.table_opt == "sparse":
+            self.uopt.group_reduce(user_ids, self.dXu, pp + 8 * o1, st)
+            self.iopt.group_reduce(iid, dXi, pp + 8 * o2, st)
+        else:
+            self.uopt.scatter(user_ids, self.dXu, st); self.uopt.sumsq(pp + 8 * o1, st)
+            self.iopt.scatter(iid, dXi, st); self.iopt.sumsq(pp + 8 * o2, st)
+        n_part = o2 + self.np_rows
+        if self.world > 1:
+            # user rows are disjoint across ranks: their squared norms add; MLP and (replicated) item
+            # parts are already global and identical on every rank
+            usq = self.part[o1:o2].sum().reshape(1)
+            all_reduce_sum_(usq, self.pg)
+            self.part[o1:o2].zero_()
+            self.part[o1] = usq[0]
+        L.check(lib.rihip_clip_coef(pp, n_part, self.max_norm, self.coef.data_ptr(), self.gnorm.data_ptr(), st),
+                "clip_coef")
+        cp = self.coef.data_ptr()
+        L.check(lib.rihip_adam_dense(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
+                                     self.flat_v.data_ptr(), self.flat_p.numel(), lr, self.b1, self.b2, self.eps,
+                                     self.wd, t, cp, st), "adam_dense")
+        self.uopt.adam(lr, self.b1, self.b2, self.eps, self.wd, t, cp, st)
+        self.iopt.adam(lr, self.b1, self.b2, self.eps, self.wd, t, cp, st)
+        return self.loss
+
+    def _sweep(self, *args) -> None:
+        ev = self.sweep_events
+        if ev is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        L.check(self.lib.rihip_inbatch_sweep(*args), "inbatch_sweep")
+        if ev is not None:
+            e1.record()
+            ev.append((e0, e1))
+
+    def _inbatch(self, st: int) -> None:
+        lib, B, d, W = self.lib, self.B, self.d, self.world
+        if W == 1:
+            L.check(lib.rihip_rowdot(self.U.data_ptr(), self.I.data_ptr(), B, 0, d, self.pos.data_ptr(), st), "rowdot")
+            self._sweep(1, self.U.data_ptr(), B, 0, self.I.data_ptr(), B, 0, d,
+                                            self.pos.data_ptr(), None, B, self.dU.data_ptr(), self.r.data_ptr(),
+                                            self.lpart.data_ptr(), st)
+            self._sweep(0, self.I.data_ptr(), B, 0, self.U.data_ptr(), B, 0, d,
+                                            self.pos.data_ptr(), self.r.data_ptr(), B, self.dI.data_ptr(), None,
+                                            None, st)
+            L.check(lib.rihip_sum_partials(self.lpart.data_ptr(), (B + 31) // 32, 1.0 / (B * (B - 1.0)),
+                                           self.loss.data_ptr(), st), "sum_partials")
+            return
+        # global in-batch negatives: all-gather both towers' outputs (4 MiB/rank at B=8192, d=128), then each rank
+        # sweeps its own users against ALL items and its own items against ALL users (no reduce-scatter).
+        G, off = W * B, self.rank * B
+        L.check(lib.rihip_rowdot(self.U.data_ptr(), self.I.data_ptr(), B, 0, d, self.pos.data_ptr(), st), "rowdot")
+        all_gather_into(self.I_all, self.I, self.pg)
+        all_gather_into(self.U_all, self.U, self.pg)
+        all_gather_into(self.pos_all, self.pos, self.pg)
+        self._sweep(1, self.U.data_ptr(), B, off, self.I_all.data_ptr(), G, 0, d,
+                                        self.pos.data_ptr(), None, G, self.dU.data_ptr(), self.r.data_ptr(),
+                                        self.lpart.data_ptr(), st)
+        all_gather_into(self.r_all, self.r, self.pg)
+        self._sweep(0, self.I.data_ptr(), B, off, self.U_all.data_ptr(), G, 0, d,
+                                        self.pos_all.data_ptr(), self.r_all.data_ptr(), G, self.dI.data_ptr(), None,
+                                        None, st)
+        L.check(lib.rihip_sum_partials(self.lpart.data_ptr(), (B + 31) // 32, 1.0 / (G * (G - 1.0)),
+                                       self.loss.data_ptr(), st), "sum_partials")
+        all_reduce_sum_(self.loss, self.pg)
+
+
+def cosine_lr(lr0: float, epoch: int, t_max: int) -> float:
+    """CosineAnnealingLR(T_max, eta_min=0) closed form; `epoch` = scheduler.step() calls so far
+    (reference steps it once per epoch: train_embeddings.py:161,197)."""
+    return 0.5 * lr0 * (1.0 + math.cos(math.pi * epoch / t_max))

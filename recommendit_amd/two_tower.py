@@ -124,14 +124,14 @@ def _run_tower(mod: "nn.Module", ids: torch.Tensor, genres: Optional[torch.Tenso
 class UserTower(nn.Module):
     """two_tower.py:19-42 -- same sub-module names, so state_dict keys match."""
 
-    def __init__(self, n_users: int, embed_dim: int, hidden_dim: int = 128, dropout: float = 0.1):
+    def __init__(self, n_users: int, embed_dim: int, hidden_dim: int = 128, dropout: float = 0.1, device=None):
         super().__init__()
-        self.embedding = nn.Embedding(n_users + 1, embed_dim, padding_idx=0)
+        self.embedding = nn.Embedding(n_users + 1, embed_dim, padding_idx=0, device=device)
         self.mlp = nn.Sequential(
-            nn.Linear(embed_dim, hidden_dim),
+            nn.Linear(embed_dim, hidden_dim, device=device),
             nn.ReLU(),
             nn.Dropout(dropout),
-            nn.Linear(hidden_dim, embed_dim),
+            nn.Linear(hidden_dim, embed_dim, device=device),
         )
         nn.init.xavier_uniform_(self.embedding.weight)  # overwrites the padding zero-row, like the reference (:36-37)
 
@@ -142,14 +142,14 @@ class UserTower(nn.Module):
 class ItemTower(nn.Module):
     """two_tower.py:45-72."""
 
-    def __init__(self, n_items: int, embed_dim: int, hidden_dim: int = 128, dropout: float = 0.1):
+    def __init__(self, n_items: int, embed_dim: int, hidden_dim: int = 128, dropout: float = 0.1, device=None):
         super().__init__()
-        self.embedding = nn.Embedding(n_items + 1, embed_dim, padding_idx=0)
+        self.embedding = nn.Embedding(n_items + 1, embed_dim, padding_idx=0, device=device)
         self.mlp = nn.Sequential(
-            nn.Linear(embed_dim + N_GENRES, hidden_dim),
+            nn.Linear(embed_dim + N_GENRES, hidden_dim, device=device),
             nn.ReLU(),
             nn.Dropout(dropout),
-            nn.Linear(hidden_dim, embed_dim),
+            nn.Linear(hidden_dim, embed_dim, device=device),
         )
         nn.init.xavier_uniform_(self.embedding.weight)
 
@@ -235,13 +235,12 @@ class TwoTowerModel(nn.Module):
         self.n_items = int(n_items)
         self.embed_dim = int(embed_dim)
         self.hidden_dim = int(hidden_dim)
-        self.user_tower = UserTower(self.n_users, embed_dim, hidden_dim, dropout)
-        self.item_tower = ItemTower(self.n_items, embed_dim, hidden_dim, dropout)
+        dev = L.device() if L.have_gpu() else None   # parameters are created directly on the HIP device
+        self.user_tower = UserTower(self.n_users, embed_dim, hidden_dim, dropout, device=dev)
+        self.item_tower = ItemTower(self.n_items, embed_dim, hidden_dim, dropout, device=dev)
         self._item_embeddings: Optional[torch.Tensor] = None
         self._item_id_to_idx: Optional[Dict[int, int]] = None
         self._idx_to_item_id: Optional[Dict[int, int]] = None
-        if L.have_gpu():
-            self.to(L.device())
 
     # -- forward / losses -------------------------------------------------------------------
     def forward(self, user_ids, pos_item_ids, pos_genre_vectors, neg_item_ids=None, neg_genre_vectors=None

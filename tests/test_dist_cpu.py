@@ -1,0 +1,58 @@
+"""CPU, world_size=2, gloo: the multi-GPU decomposition of the training step (DESIGN.md "Multi-GPU")
+-- user rows/pairs sharded, item side all-gathered, rectangular in-batch sweeps, summed partial
+norms -- reproduces the single-process result.  Compute is the NumPy oracle; the collectives are the
+same helper calls (recommendit_amd/dist_utils.py) the HIP trainer issues over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import fixtures as fx
+from oracle import two_tower_np as O
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, B, d, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from recommendit_amd.dist_utils import all_gather_into, all_reduce_sum_
+    rng = np.random.RandomState(0)
+    U, I = fx.unit_rows(rng, world * B, d), fx.unit_rows(rng, world * B, d)
+    Ul, Il = U[rank * B:(rank + 1) * B], I[rank * B:(rank + 1) * B]
+    # all-gather of tower outputs (global in-batch negatives)
+    I_all = torch.empty((world * B, d)); U_all = torch.empty((world * B, d))
+    all_gather_into(I_all, torch.from_numpy(Il)); all_gather_into(U_all, torch.from_numpy(Ul))
+    assert np.array_equal(I_all.numpy(), I) and np.array_equal(U_all.numpy(), U)
+    # rank-local sweeps: own users vs all items; own items vs all users (transpose trick via the oracle)
+    loss_l, dU_l, _ = O.in_batch_bpr_loss(Ul, I_all.numpy(), owner_offset=rank * B, n_global=world * B)
+    _, _, dI_full = O.in_batch_bpr_loss(U_all.numpy(), I_all.numpy())
+    dI_l = dI_full[rank * B:(rank + 1) * B]            # what the item-mode sweep of this rank produces
+    lt = torch.tensor([float(loss_l)], dtype=torch.float64)
+    all_reduce_sum_(lt)
+    # squared norms of disjoint (user-side) shards add up to the global norm
+    sq = torch.tensor([float((dU_l.astype(np.float64) ** 2).sum())], dtype=torch.float64)
+    all_reduce_sum_(sq)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), loss=lt.numpy(), dU=dU_l, dI=dI_l, sq=sq.numpy())
+    dist.destroy_process_group()
+
+
+def test_two_rank_inbatch_decomposition(tmp_path):
+    world, B, d = 2, 24, 16
+    mp.spawn(_worker, args=(world, _free_port(), B, d, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.RandomState(0)
+    U, I = fx.unit_rows(rng, world * B, d), fx.unit_rows(rng, world * B, d)
+    L, dU, dI = O.in_batch_bpr_loss(U, I)
+    parts = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    for p in parts:
+        assert abs(float(p["loss"][0]) - float(L)) < 1e-6
+        assert abs(float(p["sq"][0]) - float((dU.astype(np.float64) ** 2).sum())) < 1e-12
+    np.testing.assert_allclose(np.concatenate([p["dU"] for p in parts]), dU, atol=1e-9)
+    np.testing.assert_allclose(np.concatenate([p["dI"] for p in parts]), dI, atol=1e-9)
