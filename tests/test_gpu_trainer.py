@@ -96,8 +96,13 @@ def test_fused_step_variants_vs_oracle(mode, opt, cfg):
             loss = tr.step(t(u), t(p), t(gp))
         lo = _oracle_step(sd, mom, u, p, gp, n, gn, step, 5e-3, mode, opt == "sparse")
         assert abs(loss.item() - lo) < 1e-5, (step, loss.item(), lo)
+    # in-batch gradients are O(1/B^2): elements near Adam's eps=1e-8 turn ulp-level gradient differences into
+    # visible update differences (a few % of one lr-sized step), hence the looser bound for that mode
+    atol = 3e-5 if mode == "sampled" else 2.5e-4
     for k, prm in m.named_parameters():
-        np.testing.assert_allclose(prm.detach().cpu().numpy(), sd[k], atol=3e-5, rtol=0, err_msg=k)
+        got = prm.detach().cpu().numpy()
+        np.testing.assert_allclose(got, sd[k], atol=atol, rtol=0, err_msg=k)
+        assert np.mean(np.abs(got - sd[k]) > 3e-5) < 1e-3, k
 
 
 def test_device_sampler_invariants_and_short_training():
