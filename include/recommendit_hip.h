@@ -83,14 +83,19 @@ int rihip_bpr_pair_loss(const float* U, const float* P, const float* N, int64_t 
  *   rihip_rowdot        pos[i] = U[i].I[i+i_offset]
  *   rihip_inbatch_sweep mode_user=1: owners=users, swept=items -> d_owner=dU, r_out, loss_part
  *   rihip_inbatch_sweep mode_user=0: owners=items, swept=users (+pos, r_in=r) -> d_owner=dI
- *   rihip_sum_partials  loss = scale * sum(loss_part)   with scale = 1/(B(B-1))
+ *   rihip_sum_partials  loss = scale * sum(loss_part[0 .. rihip_inbatch_loss_parts))  with scale = 1/(B(B-1))
+ * workspace: floats, rihip_inbatch_workspace_floats(n_owner, n_swept, d) (slabs of the swept-range splits that
+ * keep small batches chip-filling; combined in fixed order => bitwise reproducible).
  * Global indices (owner_goff / swept_goff) place a rank's local rows inside the all-gathered
  * batch for multi-GPU in-batch negatives; n_global = B.  d in {32,64,128}. */
 int rihip_rowdot(const float* U, const float* I, int64_t B, int64_t i_offset, int d, float* pos, void* stream);
 int64_t rihip_inbatch_workspace_doubles(int64_t n_owner);
+int64_t rihip_inbatch_loss_parts(int64_t n_owner, int64_t n_swept);
+int64_t rihip_inbatch_workspace_floats(int64_t n_owner, int64_t n_swept, int d);
 int rihip_inbatch_sweep(int mode_user, const float* owners, int64_t n_owner, int64_t owner_goff, const float* swept,
                         int64_t n_swept, int64_t swept_goff, int d, const float* pos, const float* r_in,
-                        int64_t n_global, float* d_owner, float* r_out, double* loss_part, void* stream);
+                        int64_t n_global, float* d_owner, float* r_out, double* loss_part, float* workspace,
+                        void* stream);
 int rihip_sum_partials(const double* part, int64_t n, double scale, float* out, void* stream);
 
 /* ---- optimiser -----------------------------------------------------------------------------
@@ -108,12 +113,12 @@ int rihip_adam_dense(float* p, const float* g, float* m, float* v, int64_t n, fl
 /* Row-sparse path for tables too large for a dense pass per step (SURVEY.md §7 hard part 1):
  * group (id,sample) pairs by id (radix sort), sum each row's contributions in sorted order
  * (bitwise reproducible), then Adam on touched rows only.  workspace bytes from
- * rihip_rows_workspace_bytes(B); uniq int64[B]; Gc float[B,d]; part double[rihip_rows_nparts()]. */
-int64_t rihip_rows_workspace_bytes(int64_t B);
+ * rihip_rows_workspace_bytes(B, d); uniq int64[B]; Gc float[B,d]; part double[rihip_rows_nparts()]. */
+int64_t rihip_rows_workspace_bytes(int64_t B, int d);
 int rihip_rows_nparts(void);
-int rihip_rows_group(const int64_t* ids, int64_t B, int64_t* uniq, void* workspace, int64_t workspace_bytes,
+int rihip_rows_group(const int64_t* ids, int64_t B, int d, int64_t* uniq, void* workspace, int64_t workspace_bytes,
                      void* stream);
-int rihip_rows_n_unique_ptr(void* workspace, int64_t B, const int** n_unique_dev);
+int rihip_rows_n_unique_ptr(void* workspace, int64_t B, int d, const int** n_unique_dev);
 int rihip_rows_reduce(const float* dX, int64_t B, int d, const int64_t* uniq, void* workspace, float* Gc,
                       double* part, void* stream);
 int rihip_adam_rows(float* table, float* m, float* v, const int64_t* uniq, const float* Gc, int64_t B, int d,

@@ -37,18 +37,20 @@ SIGNATURES = {
     "rihip_bpr_pair_loss": (C.c_int, [vp, vp, vp, c_i64, C.c_int, vp, vp, vp, vp, vp, vp]),
     "rihip_rowdot": (C.c_int, [vp, vp, c_i64, c_i64, C.c_int, vp, vp]),
     "rihip_inbatch_workspace_doubles": (c_i64, [c_i64]),
+    "rihip_inbatch_loss_parts": (c_i64, [c_i64, c_i64]),
+    "rihip_inbatch_workspace_floats": (c_i64, [c_i64, c_i64, C.c_int]),
     "rihip_inbatch_sweep": (C.c_int, [C.c_int, vp, c_i64, c_i64, vp, c_i64, c_i64, C.c_int, vp, vp, c_i64, vp, vp, vp,
-                                      vp]),
+                                      vp, vp]),
     "rihip_sum_partials": (C.c_int, [vp, c_i64, C.c_double, vp, vp]),
     "rihip_sumsq_nparts": (C.c_int, []),
     "rihip_sumsq": (C.c_int, [vp, c_i64, vp, vp]),
     "rihip_clip_coef": (C.c_int, [vp, c_i64, C.c_float, vp, vp, vp]),
     "rihip_adam_dense": (C.c_int, [vp, vp, vp, vp, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, c_i64,
                                    vp, vp]),
-    "rihip_rows_workspace_bytes": (c_i64, [c_i64]),
+    "rihip_rows_workspace_bytes": (c_i64, [c_i64, C.c_int]),
     "rihip_rows_nparts": (C.c_int, []),
-    "rihip_rows_group": (C.c_int, [vp, c_i64, vp, vp, c_i64, vp]),
-    "rihip_rows_n_unique_ptr": (C.c_int, [vp, c_i64, C.POINTER(vp)]),
+    "rihip_rows_group": (C.c_int, [vp, c_i64, C.c_int, vp, vp, c_i64, vp]),
+    "rihip_rows_n_unique_ptr": (C.c_int, [vp, c_i64, C.c_int, C.POINTER(vp)]),
     "rihip_rows_reduce": (C.c_int, [vp, c_i64, C.c_int, vp, vp, vp, vp, vp]),
     "rihip_adam_rows": (C.c_int, [vp, vp, vp, vp, vp, c_i64, C.c_int, vp, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.c_float, c_i64, vp, vp]),

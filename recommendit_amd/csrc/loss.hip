@@ -86,25 +86,35 @@ struct SweepArgs {
   float c;           // 1/(B(B-1))
   float* dOwner;     // [No,d]
   float* r_out;      // MODE_USER: [No]
-  double* loss_part; // MODE_USER: [grid]
+  double* loss_part; // MODE_USER: [grid.x*grid.y]
+  float* slab;       // nsplit>1: [nsplit][No][d] partial owner gradients
+  float* r_part;     // nsplit>1, MODE_USER: [nsplit][No]
+  int nsplit;
 };
 
-constexpr int TS = 128;  // swept rows staged per iteration (32 per wave)
+constexpr int OW = 128;  // owners per workgroup (32 per wave)
+constexpr int TSW = 32;  // swept rows per LDS tile (shared by the 4 waves)
 
+// Workgroup = 4 waves x 32 register-stationary owners; every wave multiplies the SAME 32-row swept tile,
+// so one 16 KB (d=128) tile feeds 4 x 128 MFMAs.  Tiles are double-buffered in LDS and prefetched through
+// registers one tile ahead (loads issued before the MFMA block, LDS write after it, one barrier per tile).
+// gridDim.y splits the swept range so that small batches still fill the chip; partial owner gradients of the
+// splits are combined in fixed order by sweep_finish_kernel.
 template <int D, bool MODE_USER>
-__global__ __launch_bounds__(256) void inbatch_sweep_kernel(SweepArgs a) {
+__global__ __launch_bounds__(256, 2) void inbatch_sweep_kernel(SweepArgs a) {
   constexpr int LDY = D + 4;
   constexpr int KB = D / 8, CT = D / 32;
-  __shared__ __attribute__((aligned(16))) float Ysh[TS * LDY];  // swept tile; reused for the cross-wave reduction
-  __shared__ float posS[TS];
-  __shared__ float rS[TS];
-  __shared__ float red_r[4][32];
+  constexpr int NV = (TSW * (D / 4) + 255) / 256;  // float4 staged per thread per tile
+  __shared__ __attribute__((aligned(16))) float Ysh[2][TSW * LDY];
+  __shared__ float posS[2][TSW];
+  __shared__ float rS[2][TSW];
+  __shared__ float rsum[4][32];
   __shared__ double red_loss[4];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r31 = lane & 31, hh = lane >> 5;
-  const int64_t o_base = (int64_t)blockIdx.x * 32;
-  const int64_t o_loc = o_base + r31;           // this lane's owner (S^T accumulator column)
+  const int64_t o_base = (int64_t)blockIdx.x * OW + w * 32;
+  const int64_t o_loc = o_base + r31;  // this lane's owner (S^T accumulator column)
   const bool o_ok = o_loc < a.No;
   const int64_t o_gidx = a.o_goff + o_loc;
 
@@ -113,39 +123,66 @@ __global__ __launch_bounds__(256) void inbatch_sweep_kernel(SweepArgs a) {
   {
     const int64_t orow = o_ok ? o_loc : (a.No - 1);
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(&a.Xo[orow * D + kb * 8 + 4 * hh]);
-      xo[kb] = v;
-    }
+    for (int kb = 0; kb < KB; ++kb) xo[kb] = *reinterpret_cast<const f32x4*>(&a.Xo[orow * D + kb * 8 + 4 * hh]);
   }
   const float pos_o = (MODE_USER && o_ok) ? a.pos[o_loc] : 0.f;
 
   f32x16 out[CT];
 #pragma unroll
   for (int t = 0; t < CT; ++t) out[t] = zero16();
-  float r_acc = 0.f;     // MODE_USER: sum_s G[o][s] over this wave's share (per lane = per owner, this half's rows)
-  float loss_acc = 0.f;
+  float r_acc = 0.f, loss_acc = 0.f;
 
-  const int64_t ntiles = (a.Ns + TS - 1) / TS;
-  for (int64_t tile = 0; tile < ntiles; ++tile) {
-    const int64_t s_base = tile * TS;
-    // ---- stage swept tile (zero rows beyond Ns)
-    for (int idx = tid; idx < TS * (D / 4); idx += 256) {
+  const int64_t ntiles = (a.Ns + TSW - 1) / TSW;
+  const int64_t per = (ntiles + a.nsplit - 1) / a.nsplit;
+  const int64_t t0 = (int64_t)blockIdx.y * per;
+  const int64_t t1 = (t0 + per < ntiles) ? t0 + per : ntiles;
+
+  f32x4 stage[NV];
+  float st_pos = 0.f, st_r = 0.f;
+  auto load_tile = [&](int64_t tile) {
+    const int64_t s_base = tile * TSW;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * 256;
       const int r = idx / (D / 4), c4 = idx % (D / 4);
       const int64_t srow = s_base + r;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (srow < a.Ns) v = reinterpret_cast<const f32x4*>(a.Ys + srow * D)[c4];
-      *reinterpret_cast<f32x4*>(&Ysh[r * LDY + c4 * 4]) = v;
+      if (idx < TSW * (D / 4) && srow < a.Ns) v = reinterpret_cast<const f32x4*>(a.Ys + srow * D)[c4];
+      stage[i] = v;
     }
-    if (!MODE_USER && tid < TS) {
+    if (!MODE_USER && tid < TSW) {
       const int64_t srow = s_base + tid;
-      posS[tid] = (srow < a.Ns) ? a.pos[srow] : 0.f;
-      rS[tid] = (srow < a.Ns) ? a.r_in[srow] : 0.f;
+      st_pos = (srow < a.Ns) ? a.pos[srow] : 0.f;
+      st_r = (srow < a.Ns) ? a.r_in[srow] : 0.f;
     }
-    __syncthreads();
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * 256;
+      const int r = idx / (D / 4), c4 = idx % (D / 4);
+      if (idx < TSW * (D / 4)) *reinterpret_cast<f32x4*>(&Ysh[buf][r * LDY + c4 * 4]) = stage[i];
+    }
+    if (!MODE_USER && tid < TSW) {
+      posS[buf][tid] = st_pos;
+      rS[buf][tid] = st_r;
+    }
+  };
 
-    // ---- S^T[s][o] for this wave's 32 swept rows
-    const float* Yw = &Ysh[(w * 32) * LDY];
+  if (t0 < t1) {
+    load_tile(t0);
+    store_tile(0);
+  }
+  __syncthreads();
+
+  for (int64_t tile = t0; tile < t1; ++tile) {
+    const int cur = (int)((tile - t0) & 1);
+    const int64_t s_base = tile * TSW;
+    const bool more = (tile + 1 < t1);
+    if (more) load_tile(tile + 1);  // global loads in flight under the MFMA block below
+
+    // ---- S^T[s][o] = Y_tile . Xo^T
+    const float* Yw = Ysh[cur];
     f32x16 st = zero16();
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
@@ -155,30 +192,29 @@ __global__ __launch_bounds__(256) void inbatch_sweep_kernel(SweepArgs a) {
       st = mfma32(av.z, xo[kb].z, st);
       st = mfma32(av.w, xo[kb].w, st);
     }
-    // ---- G = sigma(z) * c  (diagonal / out-of-range masked)
+    // ---- G = sigma(z) * c  (diagonal / out-of-range masked); |z| <= 2 for unit-norm rows
     float g[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int sl = w * 32 + acc_row(r, lane);
+      const int sl = acc_row(r, lane);
       const int64_t srow = s_base + sl;
-      const int64_t s_gidx = a.s_goff + srow;
       const bool valid = o_ok && (srow < a.Ns);
-      const bool diag = (s_gidx == o_gidx);
-      const float z = st[r] - (MODE_USER ? pos_o : posS[sl]);
-      const float e = expf(-fabsf(z));
-      const float sig = ((z >= 0.f) ? 1.f : e) / (1.f + e);
+      const bool diag = (a.s_goff + srow == o_gidx);
+      const float z = st[r] - (MODE_USER ? pos_o : posS[cur][sl]);
+      const float e = __expf(-fabsf(z));
+      const float den = 1.f + e;
+      const float sig = ((z >= 0.f) ? 1.f : e) * __builtin_amdgcn_rcpf(den);
       float gv = sig * a.c;
       if (MODE_USER) {
-        const float sp = fmaxf(z, 0.f) + log1pf(e);
         if (valid && !diag) {
-          loss_acc += sp;
+          loss_acc += fmaxf(z, 0.f) + __logf(den);
           r_acc += gv;
         } else {
           gv = 0.f;
         }
       } else {
         if (!valid) gv = 0.f;
-        else if (diag) gv = -rS[sl];
+        else if (diag) gv = -rS[cur][sl];
       }
       g[r] = gv;
     }
@@ -192,54 +228,86 @@ __global__ __launch_bounds__(256) void inbatch_sweep_kernel(SweepArgs a) {
         out[t] = mfma32(g[r], bv, out[t]);
       }
     }
+    if (more) store_tile(cur ^ 1);
     __syncthreads();
   }
 
-  // ---- cross-wave reduction through LDS (fixed order w=0..3 => deterministic)
-  float* red = Ysh;  // [4][32][LDY]
-#pragma unroll
-  for (int t = 0; t < CT; ++t) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) red[(w * 32 + acc_row(r, lane)) * LDY + t * 32 + r31] = out[t][r];
-  }
-  if (MODE_USER) {
-    const float rr = r_acc + __shfl_xor(r_acc, 32, 64);  // both halves hold the same owner column
-    if (hh == 0) red_r[w][r31] = rr;
-    const float ls = wave_sum(loss_acc);
-    if (lane == 0) red_loss[w] = (double)ls;
-  }
-  __syncthreads();
+  // ---- epilogue
   {
-    const int o = tid >> 3, q = tid & 7;  // 8 threads per owner row
-    const int64_t orow = o_base + o;
-    float rsum = 0.f;
-    if (MODE_USER) rsum = red_r[0][o] + red_r[1][o] + red_r[2][o] + red_r[3][o];
-    if (orow < a.No) {
-      const int64_t drow = a.o_goff + orow - a.s_goff;  // owner's positive partner in the swept set
-      const bool has_diag = MODE_USER && drow >= 0 && drow < a.Ns;
-      for (int c4 = q; c4 < D / 4; c4 += 8) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(&red[(0 * 32 + o) * LDY + c4 * 4]);
-#pragma unroll
-        for (int ww = 1; ww < 4; ++ww) {
-          const f32x4 u = *reinterpret_cast<const f32x4*>(&red[(ww * 32 + o) * LDY + c4 * 4]);
-          v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-        }
-        if (has_diag) {  // G_ii = -sum_{j!=i} G_ij
-          const f32x4 y = reinterpret_cast<const f32x4*>(a.Ys + drow * D)[c4];
-          v.x -= rsum * y.x; v.y -= rsum * y.y; v.z -= rsum * y.z; v.w -= rsum * y.w;
-        }
-        reinterpret_cast<f32x4*>(a.dOwner + orow * D)[c4] = v;
-      }
-      if (MODE_USER && q == 0) a.r_out[orow] = rsum;
+    const float rr = r_acc + __shfl_xor(r_acc, 32, 64);  // both halves hold the same owner column
+    if (hh == 0) rsum[w][r31] = rr;
+    if (MODE_USER) {
+      const float ls = wave_sum(loss_acc);
+      if (lane == 0) red_loss[w] = (double)ls;
     }
   }
-  if (MODE_USER && tid == 0) a.loss_part[blockIdx.x] = red_loss[0] + red_loss[1] + red_loss[2] + red_loss[3];
+  __syncthreads();
+  const bool final_pass = (a.nsplit == 1);
+  float* dst = final_pass ? a.dOwner : a.slab + (size_t)blockIdx.y * a.No * D;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int o = acc_row(r, lane);
+    const int64_t orow = o_base + o;
+    if (orow < a.No) {
+      const int64_t drow = a.o_goff + orow - a.s_goff;  // owner's positive partner inside the swept set
+      const bool fix = final_pass && MODE_USER && drow >= 0 && drow < a.Ns;
+      const float rs = rsum[w][o];
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+        float v = out[t][r];
+        if (fix) v -= rs * a.Ys[drow * D + t * 32 + r31];  // G_ii = -sum_{j!=i} G_ij
+        dst[orow * D + t * 32 + r31] = v;
+      }
+    }
+  }
+  if (MODE_USER && hh == 0 && o_ok) {
+    if (final_pass) a.r_out[o_loc] = rsum[w][r31];
+    else a.r_part[(size_t)blockIdx.y * a.No + o_loc] = rsum[w][r31];
+  }
+  if (MODE_USER && tid == 0)
+    a.loss_part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = ((red_loss[0] + red_loss[1]) + red_loss[2]) + red_loss[3];
+}
+
+// nsplit>1: dOwner = sum_s slab[s] (- r * Y[diag] in user mode); r_out = sum_s r_part[s]   (fixed order)
+template <bool MODE_USER>
+__global__ __launch_bounds__(256) void sweep_finish_kernel(SweepArgs a, int d) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one float4 of one owner row
+  const int v4 = d / 4;
+  if (i >= a.No * v4) return;
+  const int64_t orow = i / v4;
+  const int c4 = (int)(i % v4);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < a.nsplit; ++s) {
+    const f32x4 u = reinterpret_cast<const f32x4*>(a.slab + ((size_t)s * a.No + orow) * d)[c4];
+    acc.x += u.x; acc.y += u.y; acc.z += u.z; acc.w += u.w;
+  }
+  if (MODE_USER) {
+    float rs = 0.f;
+    for (int s = 0; s < a.nsplit; ++s) rs += a.r_part[(size_t)s * a.No + orow];
+    const int64_t drow = a.o_goff + orow - a.s_goff;
+    if (drow >= 0 && drow < a.Ns) {
+      const f32x4 y = reinterpret_cast<const f32x4*>(a.Ys + drow * d)[c4];
+      acc.x -= rs * y.x; acc.y -= rs * y.y; acc.z -= rs * y.z; acc.w -= rs * y.w;
+    }
+    if (c4 == 0) a.r_out[orow] = rs;
+  }
+  reinterpret_cast<f32x4*>(a.dOwner + orow * d)[c4] = acc;
 }
 
 template <int D>
-void launch_sweep(bool mode_user, const SweepArgs& a, int grid, hipStream_t st) {
-  if (mode_user) hipLaunchKernelGGL((inbatch_sweep_kernel<D, true>), dim3(grid), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((inbatch_sweep_kernel<D, false>), dim3(grid), dim3(256), 0, st, a);
+void launch_sweep(bool mode_user, const SweepArgs& a, dim3 grid, hipStream_t st) {
+  if (mode_user) hipLaunchKernelGGL((inbatch_sweep_kernel<D, true>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((inbatch_sweep_kernel<D, false>), grid, dim3(256), 0, st, a);
+}
+
+int sweep_nsplit(int64_t n_owner, int64_t n_swept) {
+  const int64_t gx = (n_owner + OW - 1) / OW;
+  const int64_t tiles = (n_swept + TSW - 1) / TSW;
+  int64_t ns = (2 * RIHIP_NCU + gx - 1) / gx;  // aim at >= 2 workgroups per CU
+  if (ns > 16) ns = 16;
+  if (ns > tiles) ns = tiles;
+  if (ns < 1) ns = 1;
+  return (int)ns;
 }
 
 }  // namespace
@@ -269,12 +337,20 @@ extern "C" int rihip_rowdot(const float* U, const float* I, int64_t B, int64_t i
   return RIHIP_OK;
 }
 
-extern "C" int64_t rihip_inbatch_workspace_doubles(int64_t n_owner) { return (n_owner + 31) / 32 + 1; }
+// loss partials written per sweep (doubles) and float workspace (split slabs) needed by rihip_inbatch_sweep
+extern "C" int64_t rihip_inbatch_workspace_doubles(int64_t n_owner) { return ((n_owner + OW - 1) / OW) * 16 + 1; }
+extern "C" int64_t rihip_inbatch_loss_parts(int64_t n_owner, int64_t n_swept) {
+  return ((n_owner + OW - 1) / OW) * sweep_nsplit(n_owner, n_swept);
+}
+extern "C" int64_t rihip_inbatch_workspace_floats(int64_t n_owner, int64_t n_swept, int d) {
+  const int ns = sweep_nsplit(n_owner, n_swept);
+  return ns > 1 ? (int64_t)ns * n_owner * (d + 1) : 1;
+}
 
 extern "C" int rihip_inbatch_sweep(int mode_user, const float* owners, int64_t n_owner, int64_t owner_goff,
                                    const float* swept, int64_t n_swept, int64_t swept_goff, int d, const float* pos,
                                    const float* r_in, int64_t n_global, float* d_owner, float* r_out,
-                                   double* loss_part, void* stream) {
+                                   double* loss_part, float* workspace, void* stream) {
   RIHIP_REQUIRE(d == 32 || d == 64 || d == 128, RIHIP_ERR_SHAPE, "inbatch_sweep: unsupported embed_dim=%d", d);
   RIHIP_REQUIRE(owners && swept && pos && d_owner, RIHIP_ERR_ARG, "inbatch_sweep: null pointer");
   RIHIP_REQUIRE(mode_user ? (r_out && loss_part) : (r_in != nullptr), RIHIP_ERR_ARG,
@@ -286,12 +362,22 @@ extern "C" int rihip_inbatch_sweep(int mode_user, const float* owners, int64_t n
   a.Xo = owners; a.No = n_owner; a.o_goff = owner_goff; a.Ys = swept; a.Ns = n_swept; a.s_goff = swept_goff;
   a.pos = pos; a.r_in = r_in; a.c = (float)(1.0 / ((double)n_global * (double)(n_global - 1)));
   a.dOwner = d_owner; a.r_out = r_out; a.loss_part = loss_part;
-  const int grid = (int)((n_owner + 31) / 32);
+  a.nsplit = sweep_nsplit(n_owner, n_swept);
+  RIHIP_REQUIRE(a.nsplit == 1 || workspace, RIHIP_ERR_ARG, "inbatch_sweep: workspace required (nsplit=%d)", a.nsplit);
+  a.slab = workspace;
+  a.r_part = workspace ? workspace + (size_t)a.nsplit * n_owner * d : nullptr;
+  const dim3 grid((unsigned)((n_owner + OW - 1) / OW), (unsigned)a.nsplit);
   hipStream_t st = (hipStream_t)stream;
   if (d == 32) launch_sweep<32>(mode_user != 0, a, grid, st);
   else if (d == 64) launch_sweep<64>(mode_user != 0, a, grid, st);
   else launch_sweep<128>(mode_user != 0, a, grid, st);
   RIHIP_CHECK_LAUNCH();
+  if (a.nsplit > 1) {
+    const int64_t n4 = n_owner * (d / 4);
+    if (mode_user) hipLaunchKernelGGL((sweep_finish_kernel<true>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, a, d);
+    else hipLaunchKernelGGL((sweep_finish_kernel<false>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, a, d);
+    RIHIP_CHECK_LAUNCH();
+  }
   return RIHIP_OK;
 }
 

@@ -113,21 +113,57 @@ __global__ void seg_starts_kernel(const int64_t* __restrict__ sorted, const int*
   }
 }
 
-// one wave per unique row: Gc[u] = sum_{k in segment u} dX[perm[k]]   (sorted order => deterministic)
-__global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restrict__ dX, const int* __restrict__ perm,
-                                                          const int* __restrict__ seg_start,
-                                                          const int64_t* __restrict__ uniq,
-                                                          const int* __restrict__ n_unique, int d, float* Gc,
-                                                          double* part) {
+// Segmented row sum in two deterministic passes (a popular item can own thousands of samples of a batch;
+// one wave per segment would serialise on it):
+//  (1) one wave per block of RB consecutive SORTED positions sums each run of equal ids inside its block
+//      and stores the partial at P[position where the run starts inside the block];
+//  (2) one wave per unique row adds its partials (s0, then every multiple of RB inside the segment) in order.
+constexpr int RB = 32;
+
+__global__ __launch_bounds__(256) void rows_partial_kernel(const float* __restrict__ dX, const int* __restrict__ perm,
+                                                           const int64_t* __restrict__ sorted, int64_t B, int d,
+                                                           float* __restrict__ P) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t nblk = (B + RB - 1) / RB;
+  for (int64_t b = (int64_t)blockIdx.x * 4 + w; b < nblk; b += (int64_t)gridDim.x * 4) {
+    const int64_t p0 = b * RB, p1 = (p0 + RB < B) ? p0 + RB : B;
+    for (int c = lane; c < d; c += 64) {
+      float acc = 0.f;
+      int64_t run = p0;
+      int64_t prev = sorted[p0];
+#pragma unroll 4
+      for (int64_t i = p0; i < p1; ++i) {
+        const int64_t k = sorted[i];
+        const float v = dX[(size_t)perm[i] * d + c];
+        if (k != prev) {
+          P[(size_t)run * d + c] = acc;
+          run = i;
+          acc = v;
+          prev = k;
+        } else {
+          acc += v;
+        }
+      }
+      P[(size_t)run * d + c] = acc;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void rows_combine_kernel(const float* __restrict__ P, const int* __restrict__ seg_start,
+                                                           const int64_t* __restrict__ uniq,
+                                                           const int* __restrict__ n_unique, int d, float* Gc,
+                                                           double* part) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nu = *n_unique;
   double acc = 0.0;
   for (int u = blockIdx.x * 4 + w; u < nu; u += gridDim.x * 4) {
     const int s0 = seg_start[u], s1 = seg_start[u + 1];
     const bool pad = uniq[u] == 0;  // padding_idx row: gradient forced to zero (nn.Embedding semantics)
+    const int q0 = (s0 / RB + 1) * RB;
     for (int c = lane; c < d; c += 64) {
-      float s = 0.f;
-      for (int k = s0; k < s1; ++k) s += dX[(size_t)perm[k] * d + c];
+      float s = P[(size_t)s0 * d + c];
+#pragma unroll 8
+      for (int q = q0; q < s1; q += RB) s += P[(size_t)q * d + c];
       if (pad) s = 0.f;
       Gc[(size_t)u * d + c] = s;
       acc += (double)s * (double)s;
@@ -211,15 +247,15 @@ extern "C" int rihip_adam_dense(float* p, const float* g, float* m, float* v, in
 // ---- row-sparse path ------------------------------------------------------------------------
 // workspace layout (bytes), all 256-B aligned:
 //   keys_out int64[B] | vals_in int32[B] | perm int32[B] | flags int32[B] | seg int32[B] |
-//   seg_start int32[B+1] | n_unique int32 | rocprim temp
+//   seg_start int32[B+1] | n_unique int32 | rocprim temp | P float[B,d] (block partials)
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct RowsWs {
   int64_t* keys_out; int* vals_in; int* perm; int* flags; int* seg; int* seg_start; int* n_unique; void* temp;
-  size_t temp_bytes; size_t total;
+  float* P; size_t temp_bytes; size_t total;
 };
 
-static int rows_ws_layout(int64_t B, void* base, RowsWs* ws) {
+static int rows_ws_layout(int64_t B, int d, void* base, RowsWs* ws) {
   size_t sort_bytes = 0, scan_bytes = 0;
   hipError_t e = rocprim::radix_sort_pairs(nullptr, sort_bytes, (const int64_t*)nullptr, (int64_t*)nullptr,
                                            (const int*)nullptr, (int*)nullptr, (size_t)B);
@@ -238,23 +274,24 @@ static int rows_ws_layout(int64_t B, void* base, RowsWs* ws) {
   ws->temp = (void*)(b + off);
   ws->temp_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
   off += align256(ws->temp_bytes);
+  ws->P = (float*)(b + off); off += align256(sizeof(float) * (size_t)B * d);
   ws->total = off;
   return RIHIP_OK;
 }
 
-extern "C" int64_t rihip_rows_workspace_bytes(int64_t B) {
+extern "C" int64_t rihip_rows_workspace_bytes(int64_t B, int d) {
   RowsWs ws;
-  if (B <= 0 || rows_ws_layout(B, nullptr, &ws) != RIHIP_OK) return -1;
+  if (B <= 0 || d <= 0 || rows_ws_layout(B, d, nullptr, &ws) != RIHIP_OK) return -1;
   return (int64_t)ws.total;
 }
 
 // Groups the B (id, sample) pairs by id.  Outputs (device): uniq[<=B] unique ids ascending,
 // and inside the workspace perm / seg_start / n_unique used by rihip_rows_reduce / rihip_adam_rows.
-extern "C" int rihip_rows_group(const int64_t* ids, int64_t B, int64_t* uniq, void* workspace, int64_t workspace_bytes,
-                                void* stream) {
+extern "C" int rihip_rows_group(const int64_t* ids, int64_t B, int d, int64_t* uniq, void* workspace,
+                                int64_t workspace_bytes, void* stream) {
   RIHIP_REQUIRE(ids && uniq && workspace && B > 0 && B < (1ll << 31), RIHIP_ERR_ARG, "rows_group: bad arguments");
   RowsWs ws;
-  RIHIP_REQUIRE(rows_ws_layout(B, workspace, &ws) == RIHIP_OK, RIHIP_ERR_HIP, "rows_group: rocprim size query failed");
+  RIHIP_REQUIRE(rows_ws_layout(B, d, workspace, &ws) == RIHIP_OK, RIHIP_ERR_HIP, "rows_group: rocprim size query failed");
   RIHIP_REQUIRE((int64_t)ws.total <= workspace_bytes, RIHIP_ERR_ARG, "rows_group: workspace too small (%zu > %lld)",
                 ws.total, (long long)workspace_bytes);
   hipStream_t st = (hipStream_t)stream;
@@ -273,9 +310,9 @@ extern "C" int rihip_rows_group(const int64_t* ids, int64_t B, int64_t* uniq, vo
   return RIHIP_OK;
 }
 
-extern "C" int rihip_rows_n_unique_ptr(void* workspace, int64_t B, const int** out) {
+extern "C" int rihip_rows_n_unique_ptr(void* workspace, int64_t B, int d, const int** out) {
   RowsWs ws;
-  RIHIP_REQUIRE(rows_ws_layout(B, workspace, &ws) == RIHIP_OK, RIHIP_ERR_HIP, "rows: size query failed");
+  RIHIP_REQUIRE(rows_ws_layout(B, d, workspace, &ws) == RIHIP_OK, RIHIP_ERR_HIP, "rows: size query failed");
   *out = ws.n_unique;
   return RIHIP_OK;
 }
@@ -285,9 +322,14 @@ extern "C" int rihip_rows_reduce(const float* dX, int64_t B, int d, const int64_
                                  double* part, void* stream) {
   RIHIP_REQUIRE(dX && uniq && workspace && Gc && part && B > 0, RIHIP_ERR_ARG, "rows_reduce: bad arguments");
   RowsWs ws;
-  RIHIP_REQUIRE(rows_ws_layout(B, workspace, &ws) == RIHIP_OK, RIHIP_ERR_HIP, "rows_reduce: size query failed");
-  hipLaunchKernelGGL(rows_reduce_kernel, dim3(ROWS_GRID), dim3(256), 0, (hipStream_t)stream, dX, ws.perm, ws.seg_start,
-                     uniq, ws.n_unique, d, Gc, part);
+  RIHIP_REQUIRE(rows_ws_layout(B, d, workspace, &ws) == RIHIP_OK, RIHIP_ERR_HIP, "rows_reduce: size query failed");
+  const int64_t nblk = (B + RB - 1) / RB;
+  const int g1 = (int)((nblk + 3) / 4 < 4096 ? (nblk + 3) / 4 : 4096);
+  hipLaunchKernelGGL(rows_partial_kernel, dim3(g1), dim3(256), 0, (hipStream_t)stream, dX, ws.perm, ws.keys_out, B, d,
+                     ws.P);
+  RIHIP_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rows_combine_kernel, dim3(ROWS_GRID), dim3(256), 0, (hipStream_t)stream, ws.P, ws.seg_start, uniq,
+                     ws.n_unique, d, Gc, part);
   RIHIP_CHECK_LAUNCH();
   return RIHIP_OK;
 }
@@ -298,7 +340,7 @@ extern "C" int rihip_adam_rows(float* table, float* m, float* v, const int64_t* 
   RIHIP_REQUIRE(table && m && v && uniq && Gc && workspace && B > 0 && step >= 1, RIHIP_ERR_ARG,
                 "adam_rows: bad arguments");
   RowsWs ws;
-  RIHIP_REQUIRE(rows_ws_layout(B, workspace, &ws) == RIHIP_OK, RIHIP_ERR_HIP, "adam_rows: size query failed");
+  RIHIP_REQUIRE(rows_ws_layout(B, d, workspace, &ws) == RIHIP_OK, RIHIP_ERR_HIP, "adam_rows: size query failed");
   hipLaunchKernelGGL(adam_rows_kernel, dim3(ROWS_GRID), dim3(256), 0, (hipStream_t)stream, table, m, v, uniq, Gc,
                      ws.n_unique, d, clip_coef, make_hyper(lr, beta1, beta2, eps, weight_decay, step));
   RIHIP_CHECK_LAUNCH();

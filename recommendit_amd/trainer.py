@@ -46,7 +46,7 @@ class _RowsOpt:
         self.m = torch.zeros_like(table)
         self.v = torch.zeros_like(table)
         self.max_ids = max_ids
-        nbytes = lib.rihip_rows_workspace_bytes(max_ids)
+        nbytes = lib.rihip_rows_workspace_bytes(max_ids, self.d)
         if nbytes < 0:
             raise RuntimeError("rihip_rows_workspace_bytes failed")
         self.ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
@@ -57,7 +57,8 @@ class _RowsOpt:
         lib = L.lib()
         B = ids.numel()
         assert B <= self.max_ids
-        L.check(lib.rihip_rows_group(ids.data_ptr(), B, self.uniq.data_ptr(), self.ws.data_ptr(), self.ws.numel(), st),
+        L.check(lib.rihip_rows_group(ids.data_ptr(), B, self.d, self.uniq.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
+                                     st),
                 "rows_group")
         L.check(lib.rihip_rows_reduce(dX.data_ptr(), B, self.d, self.uniq.data_ptr(), self.ws.data_ptr(),
                                       self.Gc.data_ptr(), part_ptr, st), "rows_reduce")
@@ -164,6 +165,9 @@ class HipBPRTrainer:
         self.part = torch.zeros((self.np_mlp + 2 * self.np_rows + 8,), dtype=torch.float64, device=self.dev)
         self.lpart = torch.zeros((max(1024, self.lib.rihip_inbatch_workspace_doubles(B)),), dtype=torch.float64,
                                  device=self.dev)
+        Gall = B * (self.world if self.world > 1 else 1)
+        self.sws = torch.empty((self.lib.rihip_inbatch_workspace_floats(B, Gall, d),), **f32)
+        self.n_lparts = self.lib.rihip_inbatch_loss_parts(B, Gall)
         if loss_mode == "inbatch":
             self.pos = torch.empty((B,), **f32); self.r = torch.empty((B,), **f32)
             if self.world > 1:
@@ -276,11 +280,11 @@ class HipBPRTrainer:
             L.check(lib.rihip_rowdot(self.U.data_ptr(), self.I.data_ptr(), B, 0, d, self.pos.data_ptr(), st), "rowdot")
             self._sweep(1, self.U.data_ptr(), B, 0, self.I.data_ptr(), B, 0, d,
                                             self.pos.data_ptr(), None, B, self.dU.data_ptr(), self.r.data_ptr(),
-                                            self.lpart.data_ptr(), st)
+                                            self.lpart.data_ptr(), self.sws.data_ptr(), st)
             self._sweep(0, self.I.data_ptr(), B, 0, self.U.data_ptr(), B, 0, d,
                                             self.pos.data_ptr(), self.r.data_ptr(), B, self.dI.data_ptr(), None,
-                                            None, st)
-            L.check(lib.rihip_sum_partials(self.lpart.data_ptr(), (B + 31) // 32, 1.0 / (B * (B - 1.0)),
+                                            None, self.sws.data_ptr(), st)
+            L.check(lib.rihip_sum_partials(self.lpart.data_ptr(), self.n_lparts, 1.0 / (B * (B - 1.0)),
                                            self.loss.data_ptr(), st), "sum_partials")
             return
         # global in-batch negatives: all-gather both towers' outputs (4 MiB/rank at B=8192, d=128), then each rank
@@ -292,12 +296,12 @@ class HipBPRTrainer:
         all_gather_into(self.pos_all, self.pos, self.pg)
         self._sweep(1, self.U.data_ptr(), B, off, self.I_all.data_ptr(), G, 0, d,
                                         self.pos.data_ptr(), None, G, self.dU.data_ptr(), self.r.data_ptr(),
-                                        self.lpart.data_ptr(), st)
+                                        self.lpart.data_ptr(), self.sws.data_ptr(), st)
         all_gather_into(self.r_all, self.r, self.pg)
         self._sweep(0, self.I.data_ptr(), B, off, self.U_all.data_ptr(), G, 0, d,
                                         self.pos_all.data_ptr(), self.r_all.data_ptr(), G, self.dI.data_ptr(), None,
-                                        None, st)
-        L.check(lib.rihip_sum_partials(self.lpart.data_ptr(), (B + 31) // 32, 1.0 / (G * (G - 1.0)),
+                                        None, self.sws.data_ptr(), st)
+        L.check(lib.rihip_sum_partials(self.lpart.data_ptr(), self.n_lparts, 1.0 / (G * (G - 1.0)),
                                        self.loss.data_ptr(), st), "sum_partials")
         all_reduce_sum_(self.loss, self.pg)
 

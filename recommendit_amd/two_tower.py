@@ -195,15 +195,16 @@ def inbatch_loss_and_grads(U: torch.Tensor, I: torch.Tensor, owner_offset: int =
     L.check(lib.rihip_rowdot(Uc.data_ptr(), Ic.data_ptr(), B, 0, d, posv.data_ptr(), st), "rowdot")
     dU, dI = torch.empty_like(Uc), torch.empty_like(Ic)
     rv = torch.empty((B,), dtype=torch.float32, device=dev)
-    npart = lib.rihip_inbatch_workspace_doubles(B)
-    part = torch.zeros((npart,), dtype=torch.float64, device=dev)
+    part = torch.zeros((lib.rihip_inbatch_workspace_doubles(B),), dtype=torch.float64, device=dev)
+    ws = torch.empty((lib.rihip_inbatch_workspace_floats(B, B, d),), dtype=torch.float32, device=dev)
     loss = torch.empty((), dtype=torch.float32, device=dev)
     L.check(lib.rihip_inbatch_sweep(1, Uc.data_ptr(), B, 0, Ic.data_ptr(), B, 0, d, posv.data_ptr(), None, B,
-                                    dU.data_ptr(), rv.data_ptr(), part.data_ptr(), st), "inbatch_sweep(user)")
+                                    dU.data_ptr(), rv.data_ptr(), part.data_ptr(), ws.data_ptr(), st),
+            "inbatch_sweep(user)")
     L.check(lib.rihip_inbatch_sweep(0, Ic.data_ptr(), B, 0, Uc.data_ptr(), B, 0, d, posv.data_ptr(), rv.data_ptr(), B,
-                                    dI.data_ptr(), None, None, st), "inbatch_sweep(item)")
-    L.check(lib.rihip_sum_partials(part.data_ptr(), (B + 31) // 32, 1.0 / (B * (B - 1.0)), loss.data_ptr(), st),
-            "sum_partials")
+                                    dI.data_ptr(), None, None, ws.data_ptr(), st), "inbatch_sweep(item)")
+    L.check(lib.rihip_sum_partials(part.data_ptr(), lib.rihip_inbatch_loss_parts(B, B), 1.0 / (B * (B - 1.0)),
+                                   loss.data_ptr(), st), "sum_partials")
     return loss, dU, dI
 
 
