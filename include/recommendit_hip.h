@@ -161,6 +161,20 @@ int64_t rihip_gbdt_feature_names(void* handle, char* buf, int64_t buf_len); /* '
 int rihip_gbdt_feature_importance(void* handle, int importance_type, double* out_host);
 int rihip_gbdt_predict(void* handle, const float* X, int64_t n, int ldx, double* out, void* stream);
 
+/* ---- ranking-feature assembly ----------------------------------------------------------------
+ * Replaces RecommendationPipeline._build_ranking_features (src/serving/recommender.py:213-263) and the
+ * feature-store fetch in front of it (recommender.py:319-322) with GPU-resident float64 tables:
+ * user_tab [n_user_rows, 24] = avg_rating, log_rating_count, recency_score, gender_encoded, age_normalized,
+ * occupation_normalized, genre_pref[18]; item_tab [n_item_rows, 23] = avg_rating, log_rating_count,
+ * popularity_score, rating_stddev, year_normalized, genre_vector[18]; row 0 and absent rows = the reference's
+ * defaults.  cand_ids [nq,kc] (-1 = padding -> zero row).  col_map[nf]: canonical column index (order of
+ * src/features/feature_engineering.py:434-443) of each ranker feature, -1 => 0.0 (recommender.py:334-336).
+ * X f32 [nq*kc, nf]: values computed in float64 and cast once, like ranker.py:173. */
+int rihip_rank_features_widths(int* user_width, int* item_width, int* n_canonical);
+int rihip_rank_features_build(const double* user_tab, int64_t n_user_rows, const double* item_tab,
+                              int64_t n_item_rows, const int64_t* user_ids, const int64_t* cand_ids, int64_t nq,
+                              int kc, const int* col_map, int nf, float* X, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

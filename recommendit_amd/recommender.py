@@ -1,0 +1,130 @@
+"""GPU-resident serving stage: user tower -> inner-product retrieval -> feature assembly -> LambdaMART.
+
+Mirrors the online chain of the reference's RecommendationPipeline.get_recommendations
+(src/serving/recommender.py:269-387): A11 get_user_embedding -> R2 search(k=500) -> feature fetch
+(:319-322) -> S1 _build_ranking_features (:213-263) -> K1 ranker.predict (:338) -> nlargest(k) (:346),
+but for a BATCH of users and without leaving the device between stages.  The reference class itself stays
+the caller for single requests (drop-in through the three model classes); this module is the "next" row
+§8f-1 of SURVEY.md: a GPU feature table that supersedes the Redis MGET + the 500-iteration Python loop.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .faiss_index import FAISSIndex
+from .ranker import LightGBMRanker
+from .two_tower import N_GENRES, TwoTowerModel
+
+USER_SCALARS = [("avg_rating", 3.5), ("log_rating_count", 0.0), ("recency_score", 0.5), ("gender_encoded", 0.0),
+                ("age_normalized", 0.3), ("occupation_normalized", 0.3)]            # recommender.py:227-232
+ITEM_SCALARS = [("avg_rating", 3.5), ("log_rating_count", 0.0), ("popularity_score", 0.0), ("rating_stddev", 0.0),
+                ("year_normalized", 0.5)]                                           # recommender.py:234-238
+
+
+def feature_columns() -> List[str]:
+    """The 50 ranking columns in the order of the reference's get_feature_columns
+    (src/features/feature_engineering.py:434-443)."""
+    return (["avg_rating", "log_rating_count", "recency_score", "gender_encoded", "age_normalized",
+             "occupation_normalized", "item_avg_rating", "item_log_rating_count", "popularity_score", "rating_stddev",
+             "year_normalized", "rating_diff", "user_item_popularity_ratio", "genre_affinity"]
+            + [f"user_genre_{i}" for i in range(N_GENRES)] + [f"item_genre_{i}" for i in range(N_GENRES)])
+
+
+class GpuFeatureStore:
+    """float64 feature tables on the device; rows not loaded keep the reference's defaults.
+    Replaces RedisFeatureStore.get_user_features / get_item_features_batch (src/features/feature_store.py:113-150)
+    on the accelerated path (same keys inside the per-entity dicts)."""
+
+    def __init__(self, n_users: int, n_items: int):
+        UW, IW = 6 + N_GENRES, 5 + N_GENRES
+        self.user = np.zeros((n_users + 1, UW), dtype=np.float64)
+        self.item = np.zeros((n_items + 1, IW), dtype=np.float64)
+        self.user[:, :6] = [d for _, d in USER_SCALARS]
+        self.item[:, :5] = [d for _, d in ITEM_SCALARS]
+        self._dev: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+
+    def set_user_features(self, user_id: int, feat: Dict[str, Any]) -> None:
+        row = self.user[user_id]
+        for j, (name, dflt) in enumerate(USER_SCALARS):
+            row[j] = float(feat.get(name, dflt))
+        gp = feat.get("genre_pref", [0.0] * N_GENRES)
+        for i in range(N_GENRES):
+            row[6 + i] = float(gp[i]) if i < len(gp) else 0.0
+        self._dev = None
+
+    def set_item_features(self, item_id: int, feat: Optional[Dict[str, Any]]) -> None:
+        feat = feat or {}
+        row = self.item[item_id]
+        for j, (name, dflt) in enumerate(ITEM_SCALARS):
+            row[j] = float(feat.get(name, dflt))
+        gv = feat.get("genre_vector", [0.0] * N_GENRES)
+        for i in range(N_GENRES):
+            row[5 + i] = float(gv[i]) if i < len(gv) else 0.0
+        self._dev = None
+
+    def load_arrays(self, user_tab: Optional[np.ndarray] = None, item_tab: Optional[np.ndarray] = None) -> None:
+        """Bulk load (e.g. from the parquet feature files): arrays in the table layout, row index = id."""
+        if user_tab is not None:
+            self.user[: len(user_tab)] = user_tab
+        if item_tab is not None:
+            self.item[: len(item_tab)] = item_tab
+        self._dev = None
+
+    def device_tables(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self._dev is None:
+            dev = L.device()
+            self._dev = (torch.from_numpy(self.user).to(dev), torch.from_numpy(self.item).to(dev))
+        return self._dev
+
+
+def build_ranking_features_device(store: GpuFeatureStore, user_ids: torch.Tensor, cand_ids: torch.Tensor,
+                                  feature_names: Sequence[str]) -> torch.Tensor:
+    """X f32 [nq*kc, len(feature_names)] on device (the matrix ranker.predict would see)."""
+    lib = L.lib()
+    ut, it = store.device_tables()
+    canon = {n: i for i, n in enumerate(feature_columns())}
+    col_map = torch.tensor([canon.get(n, -1) for n in feature_names], dtype=torch.int32, device=ut.device)
+    uid = L.i64c(user_ids)
+    cand = L.i64c(cand_ids)
+    nq, kc = cand.shape
+    X = torch.empty((nq * kc, len(feature_names)), dtype=torch.float32, device=ut.device)
+    L.check(lib.rihip_rank_features_build(ut.data_ptr(), ut.shape[0], it.data_ptr(), it.shape[0], uid.data_ptr(),
+                                          cand.data_ptr(), nq, kc, col_map.data_ptr(), len(feature_names),
+                                          X.data_ptr(), L.stream_ptr()), "rank_features_build")
+    return X
+
+
+class GpuRecommendationPipeline:
+    def __init__(self, model: TwoTowerModel, index: FAISSIndex, ranker: LightGBMRanker, store: GpuFeatureStore,
+                 top_k_candidates: int = 500, top_k_results: int = 20):
+        """defaults = settings.TOP_K_CANDIDATES / TOP_K_RESULTS (src/config.py:11-12)"""
+        self.model, self.index, self.ranker, self.store = model, index, ranker, store
+        self.top_k_candidates, self.top_k_results = top_k_candidates, top_k_results
+
+    @torch.no_grad()
+    def recommend_batch(self, user_ids, k: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """-> (item_ids i64 [nq,k], ranker scores f64 [nq,k], retrieval scores f32 [nq,k]) on device; -1 padded
+        where retrieval returned fewer than k candidates.  Ties in the ranker score keep retrieval order
+        (DataFrame.nlargest(keep='first'), recommender.py:346)."""
+        k = k or self.top_k_results
+        uid = torch.as_tensor(user_ids, dtype=torch.long, device=L.device())
+        q = self.model.get_user_embeddings(uid, as_tensor=True)
+        rs, cand = self.index.batch_search_device(q, k=self.top_k_candidates, normalized=False)
+        nq, kc = cand.shape
+        X = build_ranking_features_device(self.store, uid, cand, self.ranker.feature_names)
+        scores = self.ranker.predict_device(X).view(nq, kc)
+        scores = torch.where(cand >= 0, scores, torch.full_like(scores, float("-inf")))
+        order = torch.sort(scores, dim=1, descending=True, stable=True).indices[:, :k]
+        return (torch.gather(cand, 1, order), torch.gather(scores, 1, order), torch.gather(rs, 1, order))
+
+    def get_recommendations(self, user_id: int, k: Optional[int] = None) -> List[Dict[str, Any]]:
+        ids, sc, rs = self.recommend_batch([user_id], k)
+        out = []
+        for rank, (i, s, r) in enumerate(zip(ids[0].tolist(), sc[0].tolist(), rs[0].tolist()), start=1):
+            if i >= 0:
+                out.append({"item_id": int(i), "score": float(s), "rank": rank, "retrieval_score": float(r)})
+        return out
