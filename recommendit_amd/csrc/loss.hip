@@ -96,18 +96,51 @@ constexpr int OW = 128;  // owners per workgroup (32 per wave)
 constexpr int TSW = 32;  // swept rows per LDS tile (shared by the 4 waves)
 
 // Workgroup = 4 waves x 32 register-stationary owners; every wave multiplies the SAME 32-row swept tile,
-// so one 16 KB (d=128) tile feeds 4 x 128 MFMAs.  Tiles are double-buffered in LDS and prefetched through
-// registers one tile ahead (loads issued before the MFMA block, LDS write after it, one barrier per tile).
+// so one 16 KB (d=128) tile feeds 4 x 128 MFMAs.  Software pipeline (3 LDS tile buffers, one barrier per tile):
+//   iteration t:  global loads of tile t+2 -> registers
+//                 S^T(t+1) MFMA chain  INTERLEAVED with the sigma/softplus VALU work on S^T(t)
+//                 (the chain is latency-paced at 64 cycles per MFMA, so the VALU instructions ride in its shadow)
+//                 dOwner += G(t)^T . Y(t)   (accumulator registers are the A operand)
+//                 registers -> LDS buffer of tile t+2 ; barrier
+// Tiles that contain neither the diagonal nor a ragged edge take a branch-free element path.
 // gridDim.y splits the swept range so that small batches still fill the chip; partial owner gradients of the
 // splits are combined in fixed order by sweep_finish_kernel.
+template <bool MODE_USER, bool FAST>
+__device__ __forceinline__ float sweep_elem(float s, float pos, float c, bool valid, bool diag, float r_diag,
+                                            float& loss_acc, float& r_acc) {
+  const float z = s - pos;
+  const float e = __expf(-fabsf(z));
+  const float den = 1.f + e;
+  const float sig = ((z >= 0.f) ? 1.f : e) * __builtin_amdgcn_rcpf(den);
+  float gv = sig * c;
+  if (MODE_USER) {
+    const float sp = fmaxf(z, 0.f) + __logf(den);
+    if (FAST) {
+      loss_acc += sp;
+      r_acc += gv;
+    } else if (valid && !diag) {
+      loss_acc += sp;
+      r_acc += gv;
+    } else {
+      gv = 0.f;
+    }
+  } else if (!FAST) {
+    if (!valid) gv = 0.f;
+    else if (diag) gv = r_diag;
+  }
+  return gv;
+}
+
 template <int D, bool MODE_USER>
 __global__ __launch_bounds__(256, 2) void inbatch_sweep_kernel(SweepArgs a) {
   constexpr int LDY = D + 4;
   constexpr int KB = D / 8, CT = D / 32;
+  constexpr int EPK = 16 / KB > 0 ? 16 / KB : 1;   // score elements processed per k-block of the next S chain
   constexpr int NV = (TSW * (D / 4) + 255) / 256;  // float4 staged per thread per tile
-  __shared__ __attribute__((aligned(16))) float Ysh[2][TSW * LDY];
-  __shared__ float posS[2][TSW];
-  __shared__ float rS[2][TSW];
+  static_assert(KB <= 16, "embed_dim <= 128");
+  __shared__ __attribute__((aligned(16))) float Ysh[3][TSW * LDY];
+  __shared__ float posS[3][TSW];
+  __shared__ float rS[3][TSW];
   __shared__ float rsum[4][32];
   __shared__ double red_loss[4];
 
@@ -117,6 +150,7 @@ __global__ __launch_bounds__(256, 2) void inbatch_sweep_kernel(SweepArgs a) {
   const int64_t o_loc = o_base + r31;  // this lane's owner (S^T accumulator column)
   const bool o_ok = o_loc < a.No;
   const int64_t o_gidx = a.o_goff + o_loc;
+  const bool owners_full = (o_base + 32 <= a.No);
 
   // register-stationary owner fragments: B[k][n=o] = Xo[o][k]
   f32x4 xo[KB];
@@ -169,54 +203,89 @@ __global__ __launch_bounds__(256, 2) void inbatch_sweep_kernel(SweepArgs a) {
     }
   };
 
+  if (t0 >= t1) {  // empty split (can only happen for degenerate splits): contribute zeros
+    if (hh == 0) rsum[w][r31] = 0.f;
+    if (MODE_USER && lane == 0) red_loss[w] = 0.0;
+  }
+  f32x16 st = zero16();
   if (t0 < t1) {
     load_tile(t0);
     store_tile(0);
-  }
-  __syncthreads();
-
-  for (int64_t tile = t0; tile < t1; ++tile) {
-    const int cur = (int)((tile - t0) & 1);
-    const int64_t s_base = tile * TSW;
-    const bool more = (tile + 1 < t1);
-    if (more) load_tile(tile + 1);  // global loads in flight under the MFMA block below
-
-    // ---- S^T[s][o] = Y_tile . Xo^T
-    const float* Yw = Ysh[cur];
-    f32x16 st = zero16();
+    if (t0 + 1 < t1) {
+      load_tile(t0 + 1);
+      store_tile(1);
+    }
+    __syncthreads();
+    const float* Y0 = Ysh[0];
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      const f32x4 av = *reinterpret_cast<const f32x4*>(&Yw[r31 * LDY + kb * 8 + 4 * hh]);
+    for (int kb = 0; kb < KB; ++kb) {  // S^T of the first tile (not overlapped)
+      const f32x4 av = *reinterpret_cast<const f32x4*>(&Y0[r31 * LDY + kb * 8 + 4 * hh]);
       st = mfma32(av.x, xo[kb].x, st);
       st = mfma32(av.y, xo[kb].y, st);
       st = mfma32(av.z, xo[kb].z, st);
       st = mfma32(av.w, xo[kb].w, st);
     }
-    // ---- G = sigma(z) * c  (diagonal / out-of-range masked); |z| <= 2 for unit-norm rows
+  }
+
+#pragma unroll 1
+  for (int64_t tile = t0; tile < t1; ++tile) {
+    const int it = (int)((tile - t0) % 3);
+    const int cur = it, nxt = (it + 1) % 3, pre = (it + 2) % 3;
+    const int64_t s_base = tile * TSW;
+    const bool has_next = (tile + 1 < t1);
+    const bool has_pre = (tile + 2 < t1);
+    if (has_pre) load_tile(tile + 2);  // global loads stay in flight under the MFMA blocks below
+
+    // does this tile touch the diagonal of this wave's owners or a ragged edge?
+    const int64_t sg0 = a.s_goff + s_base, og0 = a.o_goff + o_base;
+    const bool slow = !(owners_full && (s_base + TSW <= a.Ns)) || (sg0 < og0 + 32 && og0 < sg0 + TSW);
+    // 32-bit forms of the per-element tests (only evaluated on slow tiles)
+    const int64_t dd = og0 - sg0;                                        // diag  <=>  sl - r31 == dd
+    const int ddi = (dd > -64 && dd < 64) ? (int)dd : 1000;
+    const int64_t left = a.Ns - s_base;
+    const int n_valid = left < TSW ? (int)left : TSW;                    // valid <=>  sl < n_valid (and o_ok)
+    const float* Yn = Ysh[nxt];
+    const float* Yc = Ysh[cur];
+    f32x16 sn = zero16();
     float g[16];
+    if (!slow) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int sl = acc_row(r, lane);
-      const int64_t srow = s_base + sl;
-      const bool valid = o_ok && (srow < a.Ns);
-      const bool diag = (a.s_goff + srow == o_gidx);
-      const float z = st[r] - (MODE_USER ? pos_o : posS[cur][sl]);
-      const float e = __expf(-fabsf(z));
-      const float den = 1.f + e;
-      const float sig = ((z >= 0.f) ? 1.f : e) * __builtin_amdgcn_rcpf(den);
-      float gv = sig * a.c;
-      if (MODE_USER) {
-        if (valid && !diag) {
-          loss_acc += fmaxf(z, 0.f) + __logf(den);
-          r_acc += gv;
-        } else {
-          gv = 0.f;
+      for (int kb = 0; kb < KB; ++kb) {
+        if (has_next) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(&Yn[r31 * LDY + kb * 8 + 4 * hh]);
+          sn = mfma32(av.x, xo[kb].x, sn);
+          sn = mfma32(av.y, xo[kb].y, sn);
+          sn = mfma32(av.z, xo[kb].z, sn);
+          sn = mfma32(av.w, xo[kb].w, sn);
         }
-      } else {
-        if (!valid) gv = 0.f;
-        else if (diag) gv = -rS[cur][sl];
+#pragma unroll
+        for (int e = 0; e < EPK; ++e) {
+          const int r = kb * EPK + e;
+          const float pos = MODE_USER ? pos_o : posS[cur][acc_row(r, lane)];
+          g[r] = sweep_elem<MODE_USER, true>(st[r], pos, a.c, true, false, 0.f, loss_acc, r_acc);
+        }
       }
-      g[r] = gv;
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        if (has_next) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(&Yn[r31 * LDY + kb * 8 + 4 * hh]);
+          sn = mfma32(av.x, xo[kb].x, sn);
+          sn = mfma32(av.y, xo[kb].y, sn);
+          sn = mfma32(av.z, xo[kb].z, sn);
+          sn = mfma32(av.w, xo[kb].w, sn);
+        }
+#pragma unroll
+        for (int e = 0; e < EPK; ++e) {
+          const int r = kb * EPK + e;
+          const int sl = acc_row(r, lane);
+          const bool valid = o_ok && (sl < n_valid);
+          const bool diag = (sl - r31 == ddi);
+          const float pos = MODE_USER ? pos_o : posS[cur][sl];
+          const float rd = MODE_USER ? 0.f : -rS[cur][sl];
+          g[r] = sweep_elem<MODE_USER, false>(st[r], pos, a.c, valid, diag, rd, loss_acc, r_acc);
+        }
+      }
     }
     // ---- dOwner[o][c] += sum_s G[s][o] * Y[s][c]   (A operand = g registers, k = acc_row(r))
 #pragma unroll
@@ -224,16 +293,17 @@ __global__ __launch_bounds__(256, 2) void inbatch_sweep_kernel(SweepArgs a) {
       const int krow = (r & 3) + 8 * (r >> 2) + 4 * hh;
 #pragma unroll
       for (int t = 0; t < CT; ++t) {
-        const float bv = Yw[krow * LDY + t * 32 + r31];
+        const float bv = Yc[krow * LDY + t * 32 + r31];
         out[t] = mfma32(g[r], bv, out[t]);
       }
     }
-    if (more) store_tile(cur ^ 1);
+    if (has_pre) store_tile(pre);
+    st = sn;
     __syncthreads();
   }
 
   // ---- epilogue
-  {
+  if (t0 < t1) {
     const float rr = r_acc + __shfl_xor(r_acc, 32, 64);  // both halves hold the same owner column
     if (hh == 0) rsum[w][r31] = rr;
     if (MODE_USER) {

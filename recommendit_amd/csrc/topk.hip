@@ -54,20 +54,29 @@ struct ScanArgs {
   uint64_t* cand;        // [nq, cap]
   int64_t cap;
   int* count;            // [nq]
-  int nsplit;            // corpus splits (gridDim.y)
+  int nsplit;            // splits of the tile sequence (gridDim.y)
   int dense;             // 1: slot = virtual row (no atomics, count preset); 0: atomic append
   // IVF (all null/0 for brute force)
-  const int* tile_list;       // [n_tiles] list id of each 64-row tile
+  const int* tile_list;       // [n_virtual/64] list id of each 64-row granule
   const uint32_t* probe_bits; // [nq, pb_words] bitset of probed lists
   int pb_words;
   const int64_t* row_ids;     // [N] original row id per physical row (IVF), or null
+  const int* blk_tiles;       // [query blocks, n_scan_tiles] 32-row tiles some query of the block probes
+  const int* blk_ntiles;      // [query blocks]
+  int64_t n_scan_tiles;
 };
 
+constexpr int TRS = 32;  // corpus rows per LDS tile of the scan kernel
+
+// 4 waves x 32 register-stationary queries share each 32-row corpus tile.  Same software pipeline as the
+// in-batch sweep: 3 LDS buffers, tile t+2 prefetched through registers, the S chain of tile t+1 interleaved with
+// the threshold test / candidate emission of tile t, one barrier per tile.
 template <int D>
-__global__ __launch_bounds__(256) void scan_kernel(ScanArgs a) {
+__global__ __launch_bounds__(256, 2) void scan_kernel(ScanArgs a) {
   constexpr int LDX = D + 4, KB = D / 8;
-  __shared__ __attribute__((aligned(16))) float Xs[TR * LDX];
-  __shared__ int any_probe;
+  constexpr int EPK = 16 / KB > 0 ? 16 / KB : 1;
+  constexpr int NV = (TRS * (D / 4) + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float Xs[3][TRS * LDX];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r31 = lane & 31, hh = lane >> 5;
   const int64_t q = (int64_t)blockIdx.x * QB + w * 32 + r31;
@@ -79,73 +88,139 @@ __global__ __launch_bounds__(256) void scan_kernel(ScanArgs a) {
   for (int kb = 0; kb < KB; ++kb) qf[kb] = *reinterpret_cast<const f32x4*>(&a.Q[qrow * D + kb * 8 + 4 * hh]);
   const float thr = (a.thr && q_ok) ? a.thr[q] : -INFINITY;
   uint64_t* my_cand = a.cand + (size_t)qrow * a.cap;
+  const uint32_t* my_bits = a.probe_bits ? a.probe_bits + (size_t)qrow * a.pb_words : nullptr;
 
-  const int64_t n_tiles = (a.n_virtual + TR - 1) / TR;
-  const int64_t t_per = (n_tiles + a.nsplit - 1) / a.nsplit;
-  const int64_t t0 = (int64_t)blockIdx.y * t_per;
-  const int64_t t1 = (t0 + t_per < n_tiles) ? t0 + t_per : n_tiles;
+  const int* tl = a.blk_tiles ? a.blk_tiles + (size_t)blockIdx.x * a.n_scan_tiles : nullptr;
+  const int64_t n_seq = a.blk_tiles ? (int64_t)a.blk_ntiles[blockIdx.x] : (a.n_virtual + TRS - 1) / TRS;
+  const int64_t per = (n_seq + a.nsplit - 1) / a.nsplit;
+  const int64_t i0 = (int64_t)blockIdx.y * per;
+  const int64_t i1 = (i0 + per < n_seq) ? i0 + per : n_seq;
+  if (i0 >= i1) return;  // uniform across the workgroup
 
-  for (int64_t tile = t0; tile < t1; ++tile) {
-    const int64_t v_base = tile * TR;
-    bool probes = true;
-    if (a.tile_list) {  // IVF: does anyone in this block probe the tile's list?
-      const int L = a.tile_list[tile];
-      probes = q_ok && ((a.probe_bits[(size_t)q * a.pb_words + (L >> 5)] >> (L & 31)) & 1u);
-      if (tid == 0) any_probe = 0;
-      __syncthreads();
-      if (probes) any_probe = 1;
-      __syncthreads();
-      if (!any_probe) continue;  // uniform across the workgroup
-    }
-    for (int idx = tid; idx < TR * (D / 4); idx += 256) {
+  f32x4 stage[NV];
+  auto tile_at = [&](int64_t i) -> int64_t { return tl ? (int64_t)tl[i] : i; };
+  auto load_tile = [&](int64_t tile) {
+    const int64_t v_base = tile * TRS;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * 256;
       const int r = idx / (D / 4), c4 = idx % (D / 4);
       const int64_t v = v_base + r;
       f32x4 val = {0.f, 0.f, 0.f, 0.f};
-      if (v < a.n_virtual) val = reinterpret_cast<const f32x4*>(a.X + (size_t)(v * a.row_stride) * D)[c4];
-      *reinterpret_cast<f32x4*>(&Xs[r * LDX + c4 * 4]) = val;
+      if (idx < TRS * (D / 4) && v < a.n_virtual)
+        val = reinterpret_cast<const f32x4*>(a.X + (size_t)(v * a.row_stride) * D)[c4];
+      stage[i] = val;
     }
-    __syncthreads();
+  };
+  auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int rt = 0; rt < TR / 32; ++rt) {
-      f32x16 acc = zero16();
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * 256;
+      const int r = idx / (D / 4), c4 = idx % (D / 4);
+      if (idx < TRS * (D / 4)) *reinterpret_cast<f32x4*>(&Xs[buf][r * LDX + c4 * 4]) = stage[i];
+    }
+  };
+  auto emit = [&](const f32x16& acc, int64_t tile) {
+    const int64_t v_base = tile * TRS;
+    if (!q_ok) return;
+    if (a.dense) {
 #pragma unroll
-      for (int kb = 0; kb < KB; ++kb) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(&Xs[(rt * 32 + r31) * LDX + kb * 8 + 4 * hh]);
-        acc = mfma32(av.x, qf[kb].x, acc);
-        acc = mfma32(av.y, qf[kb].y, acc);
-        acc = mfma32(av.z, qf[kb].z, acc);
-        acc = mfma32(av.w, qf[kb].w, acc);
+      for (int r = 0; r < 16; ++r) {
+        const int64_t v = v_base + acc_row(r, lane);
+        if (v < a.n_virtual) my_cand[v] = make_key(acc[r], (uint32_t)v);
       }
-      if (q_ok && a.dense) {
+      return;
+    }
+    if (my_bits) {  // IVF: only queries that probe this tile's list take its rows
+      const int L = a.tile_list[tile >> 1];
+      if (!((my_bits[L >> 5] >> (L & 31)) & 1u)) return;
+    }
+    unsigned hits = 0;  // per-lane aggregation: one atomic per (query, tile) that has survivors
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t v = v_base + rt * 32 + acc_row(r, lane);
-          if (v < a.n_virtual) my_cand[v] = make_key(acc[r], (uint32_t)v);
-        }
-      } else if (q_ok && probes) {
-        // per-lane aggregation: one atomic per (query, 32-row tile) that has hits
-        unsigned hits = 0;
+    for (int r = 0; r < 16; ++r) {
+      const int64_t v = v_base + acc_row(r, lane);
+      if (v < a.n_virtual && acc[r] >= thr) hits |= (1u << r);
+    }
+    if (hits) {
+      int pos = atomicAdd(&a.count[q], __popc(hits));
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t v = v_base + rt * 32 + acc_row(r, lane);
-          if (v < a.n_virtual && acc[r] >= thr) hits |= (1u << r);
-        }
-        if (hits) {
-          int pos = atomicAdd(&a.count[q], __popc(hits));
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            if (hits & (1u << r)) {
-              const int64_t v = v_base + rt * 32 + acc_row(r, lane);
-              const int64_t rid = a.row_ids ? a.row_ids[v] : v;
-              // padding rows (rid<0) keep their slot with the lowest key so counts stay consistent
-              if (pos < a.cap) my_cand[pos] = (rid >= 0) ? make_key(acc[r], (uint32_t)rid) : 0ull;
-              ++pos;
-            }
-          }
+      for (int r = 0; r < 16; ++r) {
+        if (hits & (1u << r)) {
+          const int64_t v = v_base + acc_row(r, lane);
+          const int64_t rid = a.row_ids ? a.row_ids[v] : v;
+          // padding rows (rid<0) keep their slot with the lowest key so counts stay consistent
+          if (pos < a.cap) my_cand[pos] = (rid >= 0) ? make_key(acc[r], (uint32_t)rid) : 0ull;
+          ++pos;
         }
       }
     }
+  };
+  auto s_chain = [&](const float* Xt, f32x16& acc) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const f32x4 av = *reinterpret_cast<const f32x4*>(&Xt[r31 * LDX + kb * 8 + 4 * hh]);
+      acc = mfma32(av.x, qf[kb].x, acc);
+      acc = mfma32(av.y, qf[kb].y, acc);
+      acc = mfma32(av.z, qf[kb].z, acc);
+      acc = mfma32(av.w, qf[kb].w, acc);
+    }
+  };
+
+  load_tile(tile_at(i0));
+  store_tile(0);
+  if (i0 + 1 < i1) {
+    load_tile(tile_at(i0 + 1));
+    store_tile(1);
+  }
+  __syncthreads();
+  f32x16 st = zero16();
+  s_chain(Xs[0], st);
+
+#pragma unroll 1
+  for (int64_t i = i0; i < i1; ++i) {
+    const int it = (int)((i - i0) % 3);
+    const int nxt = (it + 1) % 3, pre = (it + 2) % 3;
+    const bool has_next = (i + 1 < i1), has_pre = (i + 2 < i1);
+    if (has_pre) load_tile(tile_at(i + 2));
+    f32x16 sn = zero16();
+    if (has_next) s_chain(Xs[nxt], sn);  // the compiler interleaves the (independent) emit below into this chain
+    emit(st, tile_at(i));
+    if (has_pre) store_tile(pre);
+    st = sn;
     __syncthreads();
+  }
+}
+
+// IVF: per query block, the ascending list of 32-row tiles whose list some query of the block probes
+__global__ __launch_bounds__(256) void ivf_block_tiles_kernel(const uint32_t* __restrict__ probe_bits, int pb_words,
+                                                              int64_t nq, const int* __restrict__ tile_list,
+                                                              int64_t n_scan_tiles, int* blk_tiles, int* blk_ntiles) {
+  __shared__ uint32_t bits[64];
+  const int tid = threadIdx.x;
+  if (tid < 64) bits[tid] = 0u;
+  __syncthreads();
+  const int64_t q0 = (int64_t)blockIdx.x * QB;
+  for (int i = tid; i < QB * pb_words; i += 256) {
+    const int64_t q = q0 + i / pb_words;
+    if (q < nq) atomicOr(&bits[i % pb_words], probe_bits[q * pb_words + (i % pb_words)]);
+  }
+  __syncthreads();
+  int* out = blk_tiles + (size_t)blockIdx.x * n_scan_tiles;
+  // wave 0 compacts in order (ballot prefix), 64 tiles per step
+  if (tid < 64) {
+    int base = 0;
+    for (int64_t t0 = 0; t0 < n_scan_tiles; t0 += 64) {
+      const int64_t t = t0 + tid;
+      bool on = false;
+      if (t < n_scan_tiles) {
+        const int L = tile_list[t >> 1];
+        on = (bits[L >> 5] >> (L & 31)) & 1u;
+      }
+      const unsigned long long m = __ballot(on);
+      if (on) out[base + __popcll(m & ((1ull << tid) - 1ull))] = (int)t;
+      base += __popcll(m);
+    }
+    if (tid == 0) blk_ntiles[blockIdx.x] = base;
   }
 }
 
@@ -438,6 +513,7 @@ struct IpIndex {
   DevBuf<int> count, fail_flags, fail_list, n_fail, fcount;
   DevBuf<float> thr, fQ;
   DevBuf<uint32_t> probe_bits;
+  DevBuf<int> blk_tiles, blk_ntiles;
   int* h_nfail = nullptr;  // pinned
 };
 
@@ -481,7 +557,7 @@ int pick_nsplit(int64_t nq, int64_t n_tiles) {
 int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, int64_t* out_r, hipStream_t st) {
   const int d = h->d;
   const int64_t Nphys = h->ivf ? h->Np : h->N;
-  const int64_t n_tiles = (Nphys + TR - 1) / TR;
+  const int64_t n_tiles = (Nphys + TRS - 1) / TRS;
   const unsigned nqb = (unsigned)((nq + 255) / 256);
   const unsigned qgrid = (unsigned)((nq + QB - 1) / QB);
   RCCHK(h->count.reserve(nq));
@@ -514,6 +590,14 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
     sa.n_virtual = Nphys; sa.row_stride = 1; sa.thr = nullptr; sa.cand = h->cand.p; sa.cap = cap; sa.dense = 0;
     sa.nsplit = pick_nsplit(nq, n_tiles);
     sa.tile_list = h->tile_list; sa.probe_bits = h->probe_bits.p; sa.pb_words = pbw; sa.row_ids = h->row_ids;
+    RIHIP_REQUIRE(pbw <= 64, RIHIP_ERR_SHAPE, "ip_index: nlist=%d > 2048 unsupported", h->nlist);
+    const int64_t n_scan_tiles = (Nphys + TRS - 1) / TRS;
+    RCCHK(h->blk_tiles.reserve((int64_t)qgrid * n_scan_tiles));
+    RCCHK(h->blk_ntiles.reserve(qgrid));
+    hipLaunchKernelGGL(ivf_block_tiles_kernel, dim3(qgrid), dim3(256), 0, st, h->probe_bits.p, pbw, nq, h->tile_list,
+                       n_scan_tiles, h->blk_tiles.p, h->blk_ntiles.p);
+    sa.blk_tiles = h->blk_tiles.p; sa.blk_ntiles = h->blk_ntiles.p; sa.n_scan_tiles = n_scan_tiles;
+    sa.nsplit = pick_nsplit(nq, (n_scan_tiles * h->nprobe) / (h->nlist > 0 ? h->nlist : 1) + 1);
     RCCHK(dispatch_scan(d, sa, dim3(qgrid, sa.nsplit), st));
     fa.cand = h->cand.p; fa.cap = cap; fa.mode = 0;
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3(256), 0, st, fa);
@@ -545,7 +629,7 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
   RCCHK(h->cand.reserve(nq * cap));
   hipLaunchKernelGGL(fill_int_kernel, dim3(nqb), dim3(256), 0, st, h->count.p, nq, (int)S);
   sa.n_virtual = S; sa.row_stride = stride; sa.thr = nullptr; sa.cand = h->scand.p; sa.cap = S; sa.dense = 1;
-  sa.nsplit = pick_nsplit(nq, (S + TR - 1) / TR);
+  sa.nsplit = pick_nsplit(nq, (S + TRS - 1) / TRS);
   RCCHK(dispatch_scan(d, sa, dim3(qgrid, sa.nsplit), st));
   fa.cand = h->scand.p; fa.cap = S; fa.mode = 1; fa.rank = rank; fa.thr_out = h->thr.p;
   hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3(256), 0, st, fa);
@@ -607,7 +691,7 @@ extern "C" int rihip_ip_index_destroy(void* handle) {
   free_index_arrays(h);
   h->cand.release(); h->scand.release(); h->fcand.release(); h->count.release(); h->fail_flags.release();
   h->fail_list.release(); h->n_fail.release(); h->fcount.release(); h->thr.release(); h->fQ.release();
-  h->probe_bits.release();
+  h->probe_bits.release(); h->blk_tiles.release(); h->blk_ntiles.release();
   if (h->h_nfail) hipHostFree(h->h_nfail);
   delete h;
   return RIHIP_OK;
