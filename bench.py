@@ -240,8 +240,51 @@ def main():
                                                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                                "frac": qps * flop_q / 1e12 / world / PEAK_F32_MFMA_TFLOPS}}
         log(f"[bench] retrieval: {qps:,.0f} q/s ({dtq / Kq * 1e3:.2f} ms per {nq} queries)")
+        # -------------------------------------------------------------- cfg5: end-to-end serve (1 GPU only)
+        if world == 1:
+            try:
+                from recommendit_amd import synthetic as GB
+                from recommendit_amd import LightGBMRanker
+                from recommendit_amd.recommender import GpuFeatureStore, GpuRecommendationPipeline, feature_columns
+                import tempfile
+                ivf = FAISSIndex(embed_dim=D, n_lists=100, n_probe=10)
+                t0 = time.perf_counter()
+                ivf.build_from_device(X, np.arange(1, args.items + 1))
+                torch.cuda.synchronize()
+                build_s = time.perf_counter() - t0
+                forest = GB.random_forest_model(500, 63, 50, seed=4, names=feature_columns())
+                with tempfile.TemporaryDirectory() as td:
+                    pth = os.path.join(td, "f.lgbm")
+                    open(pth, "w").write(GB.write_text_model(forest))
+                    ranker = LightGBMRanker.load(pth)
+                store = GpuFeatureStore(8, 8)          # tiny host tables; device tables built directly below
+                gg = torch.Generator(device=dev); gg.manual_seed(5)
+                store._dev = (torch.rand((n_users_local + 1, 24), device=dev, generator=gg, dtype=torch.float64),
+                              torch.rand((args.items + 1, 23), device=dev, generator=gg, dtype=torch.float64))
+                pipe = GpuRecommendationPipeline(model, ivf, ranker, store, top_k_candidates=K_TOP, top_k_results=20)
+                nqs = 256
+                uids = [torch.randint(1, n_users_local + 1, (nqs,), device=dev, generator=g) for _ in range(3)]
+                pipe.recommend_batch(uids[0])
+                dts = timed(lambda i: pipe.recommend_batch(uids[i % 3]), 3, 1)
+                one = uids[0][:1]
+                pipe.recommend_batch(one)
+                lat = []
+                for _ in range(20):
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                    pipe.recommend_batch(one)
+                    torch.cuda.synchronize(); lat.append((time.perf_counter() - t0) * 1e3)
+                lat.sort()
+                secondary["serve"] = {"metric": "end_to_end_recommendations_per_sec", "value": nqs * 3 / dts,
+                                      "unit": "requests/s", "batch": nqs, "single_request_ms_p50": lat[len(lat) // 2],
+                                      "single_request_ms_max": lat[-1], "ivf_build_s": build_s,
+                                      "pipeline": "user tower -> IVF-IP(100 lists, nprobe 10, 500 cands) -> feature "
+                                                  "assembly -> LambdaMART 500 trees x 63 leaves x 50 features -> top-20"}
+                log(f"[bench] serve: {nqs * 3 / dts:,.0f} req/s batched, {lat[len(lat) // 2]:.2f} ms p50 single")
+                del pipe, ivf, ranker, store
+            except Exception as e:  # the serve leg must never take the headline down
+                secondary["serve"] = {"error": repr(e)}
+                log(f"[bench] serve leg failed: {e!r}")
         del tr, model, idx, X
-
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_inbatch()

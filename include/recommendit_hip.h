@@ -47,12 +47,15 @@ int rihip_device_arch(char* buf, int buf_len);
  * (seed, (row0+row)*hidden+col) -- see oracle/two_tower_np.py:dropout_keep_mask.
  * hid [B,hidden] (post-dropout activations) and denom [B] are saved for backward (nullable).
  * err_flag (device int, nullable) is set to 1 if an id is outside [0,n_rows) (row 0 is used).
+ * workspace (nullable): rihip_tower_forward_workspace_floats(d, hidden, item) floats, 16-B aligned; holds the
+ * MFMA-fragment-major copy of W1/W2 rebuilt each call (coalesced weight loads).
  * Supported (d,hidden): see rihip_tower_supported. */
 int rihip_tower_supported(int d, int hidden);
+int64_t rihip_tower_forward_workspace_floats(int d, int hidden, int item);
 int rihip_tower_forward(const float* table, int64_t n_rows, const int64_t* ids, const float* genres, int64_t B,
                         int d, int hidden, const float* W1, const float* b1, const float* W2, const float* b2,
                         int training, float dropout_p, uint64_t seed, int64_t row0, float* out, float* hid,
-                        float* denom, int* err_flag, void* stream);
+                        float* denom, int* err_flag, float* workspace, void* stream);
 
 /* Backward of the above (autograd of two_tower.py:39-42/:68-72, run by
  * src/training/train_embeddings.py:190).  grad_out = dL/d out [B,d].

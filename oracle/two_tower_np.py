@@ -43,17 +43,30 @@ def splitmix64(x: np.ndarray) -> np.ndarray:
     return x
 
 
+def lowbias32(x: np.ndarray) -> np.ndarray:
+    x = x.astype(np.uint32)
+    with np.errstate(over="ignore"):
+        x ^= x >> np.uint32(16)
+        x = x * np.uint32(0x7FEB352D)
+        x ^= x >> np.uint32(15)
+        x = x * np.uint32(0x846CA68B)
+        x ^= x >> np.uint32(16)
+    return x
+
+
 def dropout_keep_mask(seed: int, row0: int, n_rows: int, n_cols: int, p: float) -> np.ndarray:
-    """keep[r, c] for global element index (row0 + r) * n_cols + c."""
+    """keep[r, c] for global element index (row0 + r) * n_cols + c  (recommendit_amd/csrc/common.h: rihip_keep)."""
     if p <= 0.0:
         return np.ones((n_rows, n_cols), dtype=bool)
     idx = (np.arange(row0, row0 + n_rows, dtype=np.uint64)[:, None] * np.uint64(n_cols)
            + np.arange(n_cols, dtype=np.uint64)[None, :])
+    sm = int(splitmix64(np.array([seed], dtype=np.uint64))[0])
+    lo = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32) ^ np.uint32(sm & 0xFFFFFFFF)
+    hi = (idx >> np.uint64(32)).astype(np.uint32) ^ np.uint32(sm >> 32)
     with np.errstate(over="ignore"):
-        h = splitmix64(idx ^ (np.uint64(seed) * np.uint64(0xD1342543DE82EF95)))
-    u24 = (h >> np.uint64(40)).astype(np.uint32)  # top 24 bits
+        h = lowbias32(lo ^ lowbias32(hi + np.uint32(0x9E3779B9)))
     thresh = np.uint32(min(int(p * 16777216.0), 16777215))
-    return u24 >= thresh
+    return (h >> np.uint32(8)) >= thresh
 
 
 # --------------------------------------------------------------------------- #

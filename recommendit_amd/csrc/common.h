@@ -59,7 +59,9 @@ __device__ __forceinline__ f32x16 zero16() {
   return z;
 }
 
-// ---- counter-based dropout mask (bit-identical to oracle/two_tower_np.py) ----------
+// ---- counter-based dropout mask (bit-identical to oracle/two_tower_np.py: dropout_keep_mask) ----------
+// 32-bit avalanche hash ("lowbias32") of the 64-bit element counter folded with the 64-bit seed: two 32-bit
+// multiplies per element instead of splitmix64's 64-bit ones (the mask sits in the MFMA epilogue).
 __host__ __device__ __forceinline__ uint64_t rihip_splitmix64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;
   x ^= x >> 30;
@@ -69,12 +71,23 @@ __host__ __device__ __forceinline__ uint64_t rihip_splitmix64(uint64_t x) {
   x ^= x >> 31;
   return x;
 }
-// keep element `idx` (global row * n_cols + col) with probability 1-p; thresh24 = floor(p*2^24)
-__host__ __device__ __forceinline__ bool rihip_keep(uint64_t seed_mul, uint64_t idx, uint32_t thresh24) {
-  uint64_t h = rihip_splitmix64(idx ^ seed_mul);
-  return (uint32_t)(h >> 40) >= thresh24;
+__host__ __device__ __forceinline__ uint32_t rihip_lowbias32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7feb352du;
+  x ^= x >> 15;
+  x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
 }
-__host__ __device__ __forceinline__ uint64_t rihip_seed_mul(uint64_t seed) { return seed * 0xD1342543DE82EF95ull; }
+// keep element `idx` (global row * n_cols + col) with probability 1-p; thresh24 = floor(p*2^24)
+__host__ __device__ __forceinline__ bool rihip_keep(uint64_t seed_mix, uint64_t idx, uint32_t thresh24) {
+  const uint32_t lo = (uint32_t)idx ^ (uint32_t)seed_mix;
+  const uint32_t hi = (uint32_t)(idx >> 32) ^ (uint32_t)(seed_mix >> 32);
+  const uint32_t h = rihip_lowbias32(lo ^ rihip_lowbias32(hi + 0x9E3779B9u));
+  return (h >> 8) >= thresh24;
+}
+// the 64-bit seed is scrambled once on the host
+__host__ __device__ __forceinline__ uint64_t rihip_seed_mul(uint64_t seed) { return rihip_splitmix64(seed); }
 static inline uint32_t rihip_thresh24(float p) {
   double t = (double)p * 16777216.0;
   if (t < 0) t = 0;

@@ -72,7 +72,25 @@ __device__ __forceinline__ void load_frag_cols(f32x4 (&bf)[KB], const float* __r
   }
 }
 
+// fragment-major copy of a row-major weight W[N][K] (k contiguous): Wp[(ct*KB + kb)*64 + lane] = the float4 that
+// lane `lane` of the wave owning column tile ct feeds to the 4 MFMAs of k-block kb  => one coalesced 1 KB load per
+// wave-instruction instead of 64 strided 16-B pieces
+__global__ void pack_frag_rows_kernel(const float* __restrict__ W, int N, int K, int KB, f32x4* __restrict__ Wp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (N / 32) * KB * 64) return;
+  const int lane = i & 63, kb = (i >> 6) % KB, ct = (i >> 6) / KB;
+  const int row = ct * 32 + (lane & 31), h = lane >> 5;
+  f32x4 v;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int k = kb * 8 + 4 * h + s;
+    v[s] = (k < K) ? W[(size_t)row * K + k] : 0.f;
+  }
+  Wp[i] = v;
+}
+
 struct TowerFwdArgs {
+  const f32x4 *W1p, *W2p;  // fragment-major weights (null => strided loads from W1/W2)
   const float* table;
   int64_t n_rows;
   const int64_t* ids;
@@ -135,8 +153,15 @@ __global__ __launch_bounds__(256) void tower_fwd_kernel(TowerFwdArgs a) {
   const int ct1 = T1::ct(w), ct2 = T2::ct(w);
 
   f32x4 w1f[KB1], w2f[KB2];
-  load_frag_rows<KB1>(w1f, a.W1, K1, K1, ct1 * 32 + (lane & 31), lane);
-  load_frag_rows<KB2>(w2f, a.W2, H, H, ct2 * 32 + (lane & 31), lane);
+  if (a.W1p) {
+#pragma unroll
+    for (int kb = 0; kb < KB1; ++kb) w1f[kb] = a.W1p[(ct1 * KB1 + kb) * 64 + lane];
+#pragma unroll
+    for (int kb = 0; kb < KB2; ++kb) w2f[kb] = a.W2p[(ct2 * KB2 + kb) * 64 + lane];
+  } else {
+    load_frag_rows<KB1>(w1f, a.W1, K1, K1, ct1 * 32 + (lane & 31), lane);
+    load_frag_rows<KB2>(w2f, a.W2, H, H, ct2 * 32 + (lane & 31), lane);
+  }
   const float b1v = a.b1[ct1 * 32 + (lane & 31)];
   const float b2v = a.b2[ct2 * 32 + (lane & 31)];
 
@@ -432,13 +457,23 @@ __global__ __launch_bounds__(256) void tower_bwd_kernel(TowerBwdArgs a) {
   if (tid < D) sl[H * K1 + H + D * H + tid] = ab2;
 }
 
-// grads (+)= sum over slabs; one pass, deterministic order
-__global__ void slab_reduce_kernel(const float* __restrict__ slab, int nslab, int P, int H, int K1, int D, float* dW1,
-                                   float* db1, float* dW2, float* db2, int accumulate) {
+// grads (+)= sum over slabs, two levels, fixed order => deterministic
+//   level 1: group g sums slabs g, g+G, g+2G, ...  -> part[g][P]      (grid.y = G)
+//   level 2: sums the G partials and routes element i to dW1 | db1 | dW2 | db2
+__global__ void slab_reduce1_kernel(const float* __restrict__ slab, int nslab, int P, int G, float* part) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const int g = blockIdx.y;
+  float s = 0.f;
+  for (int k = g; k < nslab; k += G) s += slab[(size_t)k * P + i];
+  part[(size_t)g * P + i] = s;
+}
+__global__ void slab_reduce2_kernel(const float* __restrict__ part, int G, int P, int H, int K1, int D, float* dW1,
+                                    float* db1, float* dW2, float* db2, int accumulate) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P) return;
   float s = 0.f;
-  for (int k = 0; k < nslab; ++k) s += slab[(size_t)k * P + i];
+  for (int g = 0; g < G; ++g) s += part[(size_t)g * P + i];
   float* dst;
   int off;
   if (i < H * K1) { dst = dW1; off = i; }
@@ -447,6 +482,7 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, int nslab, in
   else { dst = db2; off = i - H * K1 - H - D * H; }
   dst[off] = accumulate ? dst[off] + s : s;
 }
+constexpr int SLAB_GROUPS = 16;
 
 // dense embedding grad: grad[ids[b]] += dX[b]  (padding row 0 gets no gradient)
 __global__ void scatter_add_rows_kernel(float* __restrict__ grad, int64_t n_rows, const int64_t* __restrict__ ids,
@@ -492,7 +528,8 @@ extern "C" int rihip_tower_supported(int d, int hidden) {
 extern "C" int rihip_tower_forward(const float* table, int64_t n_rows, const int64_t* ids, const float* genres,
                                    int64_t B, int d, int hidden, const float* W1, const float* b1, const float* W2,
                                    const float* b2, int training, float dropout_p, uint64_t seed, int64_t row0,
-                                   float* out, float* hid, float* denom, int* err_flag, void* stream) {
+                                   float* out, float* hid, float* denom, int* err_flag, float* workspace,
+                                   void* stream) {
   RIHIP_REQUIRE(rihip_tower_supported(d, hidden), RIHIP_ERR_SHAPE,
                 "tower_forward: unsupported (embed_dim=%d, hidden_dim=%d)", d, hidden);
   RIHIP_REQUIRE(B >= 0 && n_rows > 0, RIHIP_ERR_ARG, "tower_forward: bad sizes B=%lld n_rows=%lld", (long long)B,
@@ -509,12 +546,29 @@ extern "C" int rihip_tower_forward(const float* table, int64_t n_rows, const int
   a.seed_mul = rihip_seed_mul(seed); a.thresh24 = rihip_thresh24(dropout_p);
   a.scale = 1.f / (1.f - dropout_p); a.row0 = row0; a.err_flag = err_flag;
   const int64_t ntiles = (B + TM - 1) / TM;
-  const int grid = (int)(ntiles < 2 * RIHIP_NCU ? ntiles : 2 * RIHIP_NCU);
+  const int wgs_per_cu = (d >= 128) ? 1 : 2;  // register-limited residency of the forward kernel
+  const int grid = (int)(ntiles < wgs_per_cu * RIHIP_NCU ? ntiles : wgs_per_cu * RIHIP_NCU);
   const bool item = genres != nullptr;
   hipStream_t st = (hipStream_t)stream;
+  a.W1p = nullptr; a.W2p = nullptr;
+  if (workspace) {  // re-pack the (just updated) weights fragment-major: 2 tiny launches, coalesced loads in the kernel
+    const int K1 = d + (item ? 18 : 0), KB1 = (K1 + 7) / 8, KB2 = hidden / 8;
+    RIHIP_REQUIRE(aligned16(workspace), RIHIP_ERR_ARG, "tower_forward: workspace must be 16-byte aligned");
+    f32x4* w1p = reinterpret_cast<f32x4*>(workspace);
+    f32x4* w2p = w1p + (size_t)(hidden / 32) * KB1 * 64;
+    const int n1 = (hidden / 32) * KB1 * 64, n2 = (d / 32) * KB2 * 64;
+    hipLaunchKernelGGL(pack_frag_rows_kernel, dim3((n1 + 255) / 256), dim3(256), 0, st, W1, hidden, K1, KB1, w1p);
+    hipLaunchKernelGGL(pack_frag_rows_kernel, dim3((n2 + 255) / 256), dim3(256), 0, st, W2, d, hidden, KB2, w2p);
+    a.W1p = w1p; a.W2p = w2p;
+  }
   DISPATCH_DH(launch_fwd, item, a, grid, st)
   RIHIP_CHECK_LAUNCH();
   return RIHIP_OK;
+}
+
+extern "C" int64_t rihip_tower_forward_workspace_floats(int d, int hidden, int item) {
+  const int K1 = d + (item ? 18 : 0), KB1 = (K1 + 7) / 8;
+  return (int64_t)hidden * KB1 * 8 + (int64_t)d * hidden;
 }
 
 extern "C" int64_t rihip_tower_backward_workspace_floats(int64_t B, int d, int hidden, int item) {
@@ -522,7 +576,7 @@ extern "C" int64_t rihip_tower_backward_workspace_floats(int64_t B, int d, int h
   const int64_t P = (int64_t)hidden * K1 + hidden + (int64_t)d * hidden + d;
   const int64_t ntiles = (B + TM - 1) / TM;
   const int64_t grid = ntiles < RIHIP_NCU ? ntiles : RIHIP_NCU;
-  return (grid > 0 ? grid : 1) * P;
+  return ((grid > 0 ? grid : 1) + SLAB_GROUPS) * P;
 }
 
 extern "C" int rihip_tower_backward(const float* table, int64_t n_rows, const int64_t* ids, const float* genres,
@@ -549,8 +603,11 @@ extern "C" int rihip_tower_backward(const float* table, int64_t n_rows, const in
   RIHIP_CHECK_LAUNCH();
   const int K1 = d + (item ? 18 : 0);
   const int P = hidden * K1 + hidden + d * hidden + d;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((P + 255) / 256), dim3(256), 0, st, workspace, grid, P, hidden, K1, d,
-                     dW1, db1, dW2, db2, accumulate);
+  const int G = grid < SLAB_GROUPS ? grid : SLAB_GROUPS;
+  float* part = workspace + (size_t)grid * P;
+  hipLaunchKernelGGL(slab_reduce1_kernel, dim3((P + 255) / 256, G), dim3(256), 0, st, workspace, grid, P, G, part);
+  hipLaunchKernelGGL(slab_reduce2_kernel, dim3((P + 255) / 256), dim3(256), 0, st, part, G, P, hidden, K1, d, dW1, db1,
+                     dW2, db2, accumulate);
   RIHIP_CHECK_LAUNCH();
   return RIHIP_OK;
 }

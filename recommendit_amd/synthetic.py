@@ -77,3 +77,75 @@ def write_ml1m_files(out_dir: str, ratings: pd.DataFrame, movies: pd.DataFrame, 
     with open(p / "users.dat", "w", encoding="latin-1") as f:
         for u in range(1, n_users + 1):
             f.write(f"{u}::{'MF'[u % 2]}::{[1, 18, 25, 35, 45, 50, 56][u % 7]}::{u % 21}::{10000 + u % 89999}\n")
+
+
+# ---- synthetic LambdaMART forest in LightGBM's text format (bench / tests data generator) ----------------------
+def write_text_model(model: Dict) -> str:
+    """Emit a LightGBM-format text model (the format LightGBMRanker.load reads; reference ranker.py:209,:219)."""
+    names = model["feature_names"]
+    hdr = ["tree", "version=v4", "num_class=1", "num_tree_per_iteration=1", "label_index=0",
+           f"max_feature_idx={len(names) - 1}", "objective=lambdarank",
+           "feature_names=" + " ".join(names),
+           "feature_infos=" + " ".join(["[-1e30:1e30]"] * len(names)), "tree_sizes=0", ""]
+    body = []
+    for i, t in enumerate(model["trees"]):
+        body.append(f"Tree={i}")
+        body.append(f"num_leaves={t['num_leaves']}")
+        body.append(f"num_cat={t.get('num_cat', 0)}")
+        if t["num_leaves"] > 1:
+            body.append("split_feature=" + " ".join(str(int(x)) for x in t["split_feature"]))
+            body.append("split_gain=" + " ".join("1" for _ in t["split_feature"]))
+            body.append("threshold=" + " ".join(repr(float(x)) for x in t["threshold"]))
+            body.append("decision_type=" + " ".join(str(int(x)) for x in t["decision_type"]))
+            body.append("left_child=" + " ".join(str(int(x)) for x in t["left_child"]))
+            body.append("right_child=" + " ".join(str(int(x)) for x in t["right_child"]))
+        body.append("leaf_value=" + " ".join(repr(float(x)) for x in t["leaf_value"]))
+        if t["num_leaves"] > 1:
+            if t.get("num_cat", 0) > 0:
+                body.append("cat_boundaries=" + " ".join(str(int(x)) for x in t["cat_boundaries"]))
+                body.append("cat_threshold=" + " ".join(str(int(x)) for x in t["cat_threshold"]))
+        body.append("is_linear=0")
+        body.append(f"shrinkage={t.get('shrinkage', 1.0)}")
+        body.append("")
+        body.append("")
+    tail = ["end of trees", "", "feature_importances:", "", "parameters:", "[boosting: gbdt]",
+            "end of parameters", "", "pandas_categorical:null", ""]
+    return "\n".join(hdr + body + tail)
+
+
+def random_forest_model(n_trees: int, n_leaves: int, n_features: int, seed: int = 4, names=None) -> Dict:
+    """Synthetic forest: random (unbalanced) binary trees grown leaf-by-leaf like
+    LightGBM's best-first growth; thresholds ~ N(0,1) quantiles; decision_type=2."""
+    rng = np.random.RandomState(seed)
+    names = names or [f"Column_{i}" for i in range(n_features)]
+    trees = []
+    for _ in range(n_trees):
+        nl = n_leaves
+        sf = np.zeros(nl - 1, np.int64)
+        th = np.zeros(nl - 1, np.float64)
+        lc = np.zeros(nl - 1, np.int64)
+        rc = np.zeros(nl - 1, np.int64)
+        # start: node 0 with leaves 0 (left) / 1 (right)
+        lc[0], rc[0] = ~0, ~1
+        sf[0] = rng.randint(n_features)
+        th[0] = rng.randn()
+        # parent pointers to patch when a leaf is split
+        leaf_parent = {0: (0, 0), 1: (0, 1)}  # leaf -> (node, side)
+        for new_node in range(1, nl - 1):
+            leaf = rng.choice(list(leaf_parent.keys()))
+            pn, side = leaf_parent.pop(leaf)
+            if side == 0:
+                lc[pn] = new_node
+            else:
+                rc[pn] = new_node
+            new_leaf = new_node + 1
+            lc[new_node], rc[new_node] = ~leaf, ~new_leaf
+            leaf_parent[leaf] = (new_node, 0)
+            leaf_parent[new_leaf] = (new_node, 1)
+            sf[new_node] = rng.randint(n_features)
+            th[new_node] = rng.randn()
+        trees.append(dict(num_leaves=nl, num_cat=0, split_feature=sf, threshold=th,
+                          decision_type=np.full(nl - 1, 2, np.int64), left_child=lc, right_child=rc,
+                          leaf_value=rng.randn(nl) * 0.05, shrinkage=0.05))
+    return dict(feature_names=names, max_feature_idx=n_features - 1, num_class=1,
+                num_tree_per_iteration=1, average_output=False, objective="lambdarank", trees=trees)

@@ -160,6 +160,8 @@ class HipBPRTrainer:
         nws = max(self.lib.rihip_tower_backward_workspace_floats(B, d, H, 0),
                   self.lib.rihip_tower_backward_workspace_floats(nI, d, H, 1))
         self.bws = torch.empty((nws,), **f32)
+        self.fws_u = torch.empty((self.lib.rihip_tower_forward_workspace_floats(d, H, 0),), **f32)
+        self.fws_i = torch.empty((self.lib.rihip_tower_forward_workspace_floats(d, H, 1),), **f32)
         self.np_mlp = self.lib.rihip_sumsq_nparts()
         self.np_rows = self.lib.rihip_rows_nparts() if table_opt == "sparse" else self.np_mlp
         self.part = torch.zeros((self.np_mlp + 2 * self.np_rows + 8,), dtype=torch.float64, device=self.dev)
@@ -187,7 +189,8 @@ class HipBPRTrainer:
                                              self.pv[keys[1]].data_ptr(), self.pv[keys[2]].data_ptr(),
                                              self.pv[keys[3]].data_ptr(), 1 if training else 0, self.p_drop, seed, 0,
                                              out.data_ptr(), hid.data_ptr(), den.data_ptr(), self.err.data_ptr(),
-                                             self._st), "tower_forward")
+                                             (self.fws_u if genres is None else self.fws_i).data_ptr(), self._st),
+                "tower_forward")
 
     def _bwd(self, table, ids, genres, keys, gout, out, den, hid, dX):
         scale = 1.0 / (1.0 - self.p_drop) if (self.model.training and self.p_drop > 0) else 1.0

@@ -69,10 +69,13 @@ class _TowerFn(torch.autograd.Function):
         hid = torch.empty((B, H), dtype=torch.float32, device=dev)
         denom = torch.empty((B,), dtype=torch.float32, device=dev)
         err = torch.zeros((1,), dtype=torch.int32, device=dev)
+        ws = torch.empty((lib.rihip_tower_forward_workspace_floats(d, H, 0 if g_d is None else 1),),
+                         dtype=torch.float32, device=dev)
         L.check(lib.rihip_tower_forward(table_c.data_ptr(), table_c.shape[0], ids_d.data_ptr(), L.ptr(g_d), B, d, H,
                                         W1c.data_ptr(), b1c.data_ptr(), W2c.data_ptr(), b2c.data_ptr(),
                                         1 if training else 0, float(p), seed, 0, out.data_ptr(), hid.data_ptr(),
-                                        denom.data_ptr(), err.data_ptr(), L.stream_ptr()), "tower_forward")
+                                        denom.data_ptr(), err.data_ptr(), ws.data_ptr(), L.stream_ptr()),
+                "tower_forward")
         ctx.save_for_backward(table_c, W1c, W2c, ids_d, g_d, out, hid, denom)
         ctx.scale = 1.0 / (1.0 - p) if (training and p > 0) else 1.0
         if _CHECK_IDS and int(err.item()) != 0:
