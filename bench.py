@@ -194,10 +194,28 @@ def main():
                 "executed_flop_per_launch": 4.0 * B * G * D}
     log(f"[bench] in-batch: {pairs_per_s:,.0f} pairs/s, {dt / K * 1e3:.2f} ms/step, loss {loss:.4f}, "
         f"sweep {t_launch * 1e3:.3f} ms/launch = {achieved:.1f} TFLOP/s algorithmic")
+    secondary = {}
+    if not args.no_secondary:
+        # ---------------------------------------------------------- same step with the split-bf16 ("bf16x3") sweep
+        tr.inbatch_precision = 1
+        for i in range(W):
+            step(i)
+        ev2 = []
+        tr.sweep_events = ev2
+        dtb = timed(lambda i: step(W + i), K, world)
+        tr.sweep_events = None
+        ms2 = [a_.elapsed_time(b_) for a_, b_ in ev2]
+        tl2 = sum(ms2) / 1e3 / max(len(ms2), 1)
+        secondary["inbatch_bf16x3"] = {
+            "metric": "bpr_pairs_per_sec", "value": G * K / dtb, "unit": "pairs/s", "ms_per_step": dtb / K * 1e3,
+            "dtype": "bf16x3 split products (hi.hi+hi.lo+lo.hi), f32 accumulate", "sweep_launch_ms": tl2 * 1e3,
+            "algorithmic_tflops": flop_launch / tl2 / 1e12 if tl2 > 0 else 0.0, "final_loss": float(tr.loss.item()),
+            "note": "optional precision mode of the dominant kernel; relative product error ~2^-16; same tests, "
+                    "looser tolerance (tests/test_gpu_towers.py::test_inbatch_bf16x3_precision_mode)"}
+        log(f"[bench] in-batch bf16x3: {G * K / dtb:,.0f} pairs/s, {dtb / K * 1e3:.2f} ms/step, sweep {tl2 * 1e3:.3f} ms/launch")
     del tr, model, batches
     torch.cuda.empty_cache()
 
-    secondary = {}
     if not args.no_secondary:
         # -------------------------------------------------------------- sampled-negative BPR (reference's mode)
         Bs = 65536 // world

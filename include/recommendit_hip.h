@@ -89,6 +89,8 @@ int rihip_bpr_pair_loss(const float* U, const float* P, const float* N, int64_t 
  *   rihip_sum_partials  loss = scale * sum(loss_part[0 .. rihip_inbatch_loss_parts))  with scale = 1/(B(B-1))
  * workspace: floats, rihip_inbatch_workspace_floats(n_owner, n_swept, d) (slabs of the swept-range splits that
  * keep small batches chip-filling; combined in fixed order => bitwise reproducible).
+ * precision: 0 = exact-f32 MFMA (default, the parity reference); 1 = "bf16x3": operands split hi+lo in bf16,
+ * products hi.hi+hi.lo+lo.hi on bf16 MFMA with f32 accumulation (relative product error ~2^-16).
  * Global indices (owner_goff / swept_goff) place a rank's local rows inside the all-gathered
  * batch for multi-GPU in-batch negatives; n_global = B.  d in {32,64,128}. */
 int rihip_rowdot(const float* U, const float* I, int64_t B, int64_t i_offset, int d, float* pos, void* stream);
@@ -98,7 +100,7 @@ int64_t rihip_inbatch_workspace_floats(int64_t n_owner, int64_t n_swept, int d);
 int rihip_inbatch_sweep(int mode_user, const float* owners, int64_t n_owner, int64_t owner_goff, const float* swept,
                         int64_t n_swept, int64_t swept_goff, int d, const float* pos, const float* r_in,
                         int64_t n_global, float* d_owner, float* r_out, double* loss_part, float* workspace,
-                        void* stream);
+                        int precision, void* stream);
 int rihip_sum_partials(const double* part, int64_t n, double scale, float* out, void* stream);
 
 /* ---- optimiser -----------------------------------------------------------------------------

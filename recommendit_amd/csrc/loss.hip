@@ -11,6 +11,9 @@
 //    (S is recomputed; 8 B^2 d FLOP instead of 6 B^2 d, but zero atomic traffic).
 #include "common.h"
 #include "recommendit_hip.h"
+#include "loss_sweep_args.h"
+
+void rihip_launch_sweep_bf16x3(int d, bool mode_user, const SweepArgs& a, dim3 grid, hipStream_t st);
 
 namespace {
 
@@ -74,63 +77,6 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ U
 // ------------------------------------------------------------------------------------------
 // in-batch sweep
 // ------------------------------------------------------------------------------------------
-struct SweepArgs {
-  const float* Xo;   // owners [No,d]
-  int64_t No;
-  int64_t o_goff;    // global index of owner 0
-  const float* Ys;   // swept [Ns,d]
-  int64_t Ns;
-  int64_t s_goff;    // global index of swept 0
-  const float* pos;  // MODE_USER: [No] by owner ; MODE_ITEM: [Ns] by swept (user) index
-  const float* r_in; // MODE_ITEM: [Ns] rowsum of G per user
-  float c;           // 1/(B(B-1))
-  float* dOwner;     // [No,d]
-  float* r_out;      // MODE_USER: [No]
-  double* loss_part; // MODE_USER: [grid.x*grid.y]
-  float* slab;       // nsplit>1: [nsplit][No][d] partial owner gradients
-  float* r_part;     // nsplit>1, MODE_USER: [nsplit][No]
-  int nsplit;
-};
-
-constexpr int OW = 128;  // owners per workgroup (32 per wave)
-constexpr int TSW = 32;  // swept rows per LDS tile (shared by the 4 waves)
-
-// Workgroup = 4 waves x 32 register-stationary owners; every wave multiplies the SAME 32-row swept tile,
-// so one 16 KB (d=128) tile feeds 4 x 128 MFMAs.  Software pipeline (3 LDS tile buffers, one barrier per tile):
-//   iteration t:  global loads of tile t+2 -> registers
-//                 S^T(t+1) MFMA chain  INTERLEAVED with the sigma/softplus VALU work on S^T(t)
-//                 (the chain is latency-paced at 64 cycles per MFMA, so the VALU instructions ride in its shadow)
-//                 dOwner += G(t)^T . Y(t)   (accumulator registers are the A operand)
-//                 registers -> LDS buffer of tile t+2 ; barrier
-// Tiles that contain neither the diagonal nor a ragged edge take a branch-free element path.
-// gridDim.y splits the swept range so that small batches still fill the chip; partial owner gradients of the
-// splits are combined in fixed order by sweep_finish_kernel.
-template <bool MODE_USER, bool FAST>
-__device__ __forceinline__ float sweep_elem(float s, float pos, float c, bool valid, bool diag, float r_diag,
-                                            float& loss_acc, float& r_acc) {
-  const float z = s - pos;
-  const float e = __expf(-fabsf(z));
-  const float den = 1.f + e;
-  const float sig = ((z >= 0.f) ? 1.f : e) * __builtin_amdgcn_rcpf(den);
-  float gv = sig * c;
-  if (MODE_USER) {
-    const float sp = fmaxf(z, 0.f) + __logf(den);
-    if (FAST) {
-      loss_acc += sp;
-      r_acc += gv;
-    } else if (valid && !diag) {
-      loss_acc += sp;
-      r_acc += gv;
-    } else {
-      gv = 0.f;
-    }
-  } else if (!FAST) {
-    if (!valid) gv = 0.f;
-    else if (diag) gv = r_diag;
-  }
-  return gv;
-}
-
 template <int D, bool MODE_USER>
 __global__ __launch_bounds__(256, 2) void inbatch_sweep_kernel(SweepArgs a) {
   constexpr int LDY = D + 4;
@@ -420,8 +366,10 @@ extern "C" int64_t rihip_inbatch_workspace_floats(int64_t n_owner, int64_t n_swe
 extern "C" int rihip_inbatch_sweep(int mode_user, const float* owners, int64_t n_owner, int64_t owner_goff,
                                    const float* swept, int64_t n_swept, int64_t swept_goff, int d, const float* pos,
                                    const float* r_in, int64_t n_global, float* d_owner, float* r_out,
-                                   double* loss_part, float* workspace, void* stream) {
+                                   double* loss_part, float* workspace, int precision, void* stream) {
   RIHIP_REQUIRE(d == 32 || d == 64 || d == 128, RIHIP_ERR_SHAPE, "inbatch_sweep: unsupported embed_dim=%d", d);
+  RIHIP_REQUIRE(precision == 0 || precision == 1, RIHIP_ERR_ARG, "inbatch_sweep: precision=%d (0=f32, 1=bf16x3)",
+                precision);
   RIHIP_REQUIRE(owners && swept && pos && d_owner, RIHIP_ERR_ARG, "inbatch_sweep: null pointer");
   RIHIP_REQUIRE(mode_user ? (r_out && loss_part) : (r_in != nullptr), RIHIP_ERR_ARG,
                 "inbatch_sweep: mode-specific pointer missing");
@@ -438,7 +386,8 @@ extern "C" int rihip_inbatch_sweep(int mode_user, const float* owners, int64_t n
   a.r_part = workspace ? workspace + (size_t)a.nsplit * n_owner * d : nullptr;
   const dim3 grid((unsigned)((n_owner + OW - 1) / OW), (unsigned)a.nsplit);
   hipStream_t st = (hipStream_t)stream;
-  if (d == 32) launch_sweep<32>(mode_user != 0, a, grid, st);
+  if (precision == 1) rihip_launch_sweep_bf16x3(d, mode_user != 0, a, grid, st);
+  else if (d == 32) launch_sweep<32>(mode_user != 0, a, grid, st);
   else if (d == 64) launch_sweep<64>(mode_user != 0, a, grid, st);
   else launch_sweep<128>(mode_user != 0, a, grid, st);
   RIHIP_CHECK_LAUNCH();

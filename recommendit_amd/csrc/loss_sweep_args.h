@@ -1,0 +1,61 @@
+// Shared between the exact-f32 (loss.hip) and split-bf16 (loss_bf16.hip) in-batch sweep kernels.
+#pragma once
+#include "common.h"
+
+struct SweepArgs {
+  const float* Xo;   // owners [No,d]
+  int64_t No;
+  int64_t o_goff;    // global index of owner 0
+  const float* Ys;   // swept [Ns,d]
+  int64_t Ns;
+  int64_t s_goff;    // global index of swept 0
+  const float* pos;  // MODE_USER: [No] by owner ; MODE_ITEM: [Ns] by swept (user) index
+  const float* r_in; // MODE_ITEM: [Ns] rowsum of G per user
+  float c;           // 1/(B(B-1))
+  float* dOwner;     // [No,d]
+  float* r_out;      // MODE_USER: [No]
+  double* loss_part; // MODE_USER: [grid.x*grid.y]
+  float* slab;       // nsplit>1: [nsplit][No][d] partial owner gradients
+  float* r_part;     // nsplit>1, MODE_USER: [nsplit][No]
+  int nsplit;
+};
+
+constexpr int OW = 128;  // owners per workgroup (32 per wave)
+constexpr int TSW = 32;  // swept rows per LDS tile (shared by the 4 waves)
+
+// Workgroup = 4 waves x 32 register-stationary owners; every wave multiplies the SAME 32-row swept tile,
+// so one 16 KB (d=128) tile feeds 4 x 128 MFMAs.  Software pipeline (3 LDS tile buffers, one barrier per tile):
+//   iteration t:  global loads of tile t+2 -> registers
+//                 S^T(t+1) MFMA chain  INTERLEAVED with the sigma/softplus VALU work on S^T(t)
+//                 (the chain is latency-paced at 64 cycles per MFMA, so the VALU instructions ride in its shadow)
+//                 dOwner += G(t)^T . Y(t)   (accumulator registers are the A operand)
+//                 registers -> LDS buffer of tile t+2 ; barrier
+// Tiles that contain neither the diagonal nor a ragged edge take a branch-free element path.
+// gridDim.y splits the swept range so that small batches still fill the chip; partial owner gradients of the
+// splits are combined in fixed order by sweep_finish_kernel.
+template <bool MODE_USER, bool FAST>
+__device__ __forceinline__ float sweep_elem(float s, float pos, float c, bool valid, bool diag, float r_diag,
+                                            float& loss_acc, float& r_acc) {
+  const float z = s - pos;
+  const float e = __expf(-fabsf(z));
+  const float den = 1.f + e;
+  const float sig = ((z >= 0.f) ? 1.f : e) * __builtin_amdgcn_rcpf(den);
+  float gv = sig * c;
+  if (MODE_USER) {
+    const float sp = fmaxf(z, 0.f) + __logf(den);
+    if (FAST) {
+      loss_acc += sp;
+      r_acc += gv;
+    } else if (valid && !diag) {
+      loss_acc += sp;
+      r_acc += gv;
+    } else {
+      gv = 0.f;
+    }
+  } else if (!FAST) {
+    if (!valid) gv = 0.f;
+    else if (diag) gv = r_diag;
+  }
+  return gv;
+}
+

@@ -96,7 +96,8 @@ class _DenseOpt:
 class HipBPRTrainer:
     def __init__(self, model: TwoTowerModel, batch_size: int, lr: float = 1e-3, weight_decay: float = 1e-5,
                  betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = 1.0, loss_mode: str = "sampled",
-                 table_opt: str = "dense", seed: int = 0, process_group=None, user_row_offset: int = 0):
+                 table_opt: str = "dense", seed: int = 0, process_group=None, user_row_offset: int = 0,
+                 inbatch_precision: int = 0):
         assert loss_mode in ("sampled", "inbatch") and table_opt in ("dense", "sparse")
         self.lib = L.lib()
         self.model = model
@@ -106,6 +107,7 @@ class HipBPRTrainer:
         self.loss_mode, self.table_opt = loss_mode, table_opt
         self.step_count = 0
         self.seed = seed
+        self.inbatch_precision = int(inbatch_precision)  # 0 = exact f32 MFMA, 1 = split-bf16 (bf16x3)
         self.sweep_events = None  # bench hook: list collecting (start, end) events around every sweep launch
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
@@ -283,10 +285,10 @@ class HipBPRTrainer:
             L.check(lib.rihip_rowdot(self.U.data_ptr(), self.I.data_ptr(), B, 0, d, self.pos.data_ptr(), st), "rowdot")
             self._sweep(1, self.U.data_ptr(), B, 0, self.I.data_ptr(), B, 0, d,
                                             self.pos.data_ptr(), None, B, self.dU.data_ptr(), self.r.data_ptr(),
-                                            self.lpart.data_ptr(), self.sws.data_ptr(), st)
+                                            self.lpart.data_ptr(), self.sws.data_ptr(), self.inbatch_precision, st)
             self._sweep(0, self.I.data_ptr(), B, 0, self.U.data_ptr(), B, 0, d,
                                             self.pos.data_ptr(), self.r.data_ptr(), B, self.dI.data_ptr(), None,
-                                            None, self.sws.data_ptr(), st)
+                                            None, self.sws.data_ptr(), self.inbatch_precision, st)
             L.check(lib.rihip_sum_partials(self.lpart.data_ptr(), self.n_lparts, 1.0 / (B * (B - 1.0)),
                                            self.loss.data_ptr(), st), "sum_partials")
             return
@@ -299,11 +301,11 @@ class HipBPRTrainer:
         all_gather_into(self.pos_all, self.pos, self.pg)
         self._sweep(1, self.U.data_ptr(), B, off, self.I_all.data_ptr(), G, 0, d,
                                         self.pos.data_ptr(), None, G, self.dU.data_ptr(), self.r.data_ptr(),
-                                        self.lpart.data_ptr(), self.sws.data_ptr(), st)
+                                        self.lpart.data_ptr(), self.sws.data_ptr(), self.inbatch_precision, st)
         all_gather_into(self.r_all, self.r, self.pg)
         self._sweep(0, self.I.data_ptr(), B, off, self.U_all.data_ptr(), G, 0, d,
                                         self.pos_all.data_ptr(), self.r_all.data_ptr(), G, self.dI.data_ptr(), None,
-                                        None, self.sws.data_ptr(), st)
+                                        None, self.sws.data_ptr(), self.inbatch_precision, st)
         L.check(lib.rihip_sum_partials(self.lpart.data_ptr(), self.n_lparts, 1.0 / (G * (G - 1.0)),
                                        self.loss.data_ptr(), st), "sum_partials")
         all_reduce_sum_(self.loss, self.pg)

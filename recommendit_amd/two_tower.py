@@ -184,7 +184,7 @@ class _BprPairFn(torch.autograd.Function):
         return tuple((t * g).to(dv) for t, dv in zip((dU, dP, dN), ctx.in_devs))
 
 
-def inbatch_loss_and_grads(U: torch.Tensor, I: torch.Tensor, owner_offset: int = 0,
+def inbatch_loss_and_grads(U: torch.Tensor, I: torch.Tensor, precision: int = 0, owner_offset: int = 0,
                            n_global: Optional[int] = None, pos: Optional[torch.Tensor] = None,
                            r: Optional[torch.Tensor] = None, users_global: Optional[torch.Tensor] = None,
                            item_owner_offset: Optional[int] = None):
@@ -202,10 +202,10 @@ def inbatch_loss_and_grads(U: torch.Tensor, I: torch.Tensor, owner_offset: int =
     ws = torch.empty((lib.rihip_inbatch_workspace_floats(B, B, d),), dtype=torch.float32, device=dev)
     loss = torch.empty((), dtype=torch.float32, device=dev)
     L.check(lib.rihip_inbatch_sweep(1, Uc.data_ptr(), B, 0, Ic.data_ptr(), B, 0, d, posv.data_ptr(), None, B,
-                                    dU.data_ptr(), rv.data_ptr(), part.data_ptr(), ws.data_ptr(), st),
+                                    dU.data_ptr(), rv.data_ptr(), part.data_ptr(), ws.data_ptr(), precision, st),
             "inbatch_sweep(user)")
     L.check(lib.rihip_inbatch_sweep(0, Ic.data_ptr(), B, 0, Uc.data_ptr(), B, 0, d, posv.data_ptr(), rv.data_ptr(), B,
-                                    dI.data_ptr(), None, None, ws.data_ptr(), st), "inbatch_sweep(item)")
+                                    dI.data_ptr(), None, None, ws.data_ptr(), precision, st), "inbatch_sweep(item)")
     L.check(lib.rihip_sum_partials(part.data_ptr(), lib.rihip_inbatch_loss_parts(B, B), 1.0 / (B * (B - 1.0)),
                                    loss.data_ptr(), st), "sum_partials")
     return loss, dU, dI

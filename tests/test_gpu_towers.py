@@ -241,3 +241,23 @@ def test_g5_g6_inference_and_reference_checkpoint(golden_dir, tmp_path):
     m2 = TwoTowerModel.load(str(tmp_path / "tt.pt"))
     assert (m2.n_users, m2.n_items, m2.embed_dim, m2.hidden_dim) == (nu, ni, d, H)
     np.testing.assert_allclose(m2.get_user_embedding(7), g["user7"], atol=2e-6)
+
+
+@pytest.mark.parametrize("B,d", [(33, 32), (130, 64), (500, 128), (2048, 128)])
+def test_inbatch_bf16x3_precision_mode(B, d):
+    """Optional split-bf16 sweep (hi.hi + hi.lo + lo.hi on bf16 MFMA, f32 accumulate): same results as the exact
+    path within the split's 2^-16 product error."""
+    from recommendit_amd.two_tower import inbatch_loss_and_grads
+    rng = np.random.RandomState(B + 1)
+    U, I = fx.unit_rows(rng, B, d), fx.unit_rows(rng, B, d)
+    l1, dU1, dI1 = inbatch_loss_and_grads(t(U), t(I), precision=1)
+    l2, dU2, dI2 = inbatch_loss_and_grads(t(U), t(I), precision=1)
+    assert torch.equal(dU1, dU2) and torch.equal(dI1, dI2) and torch.equal(l1, l2)   # still deterministic
+    lo, dUo, dIo = O.in_batch_bpr_loss(U, I)
+    assert abs(l1.item() - float(lo)) < 5e-6
+    np.testing.assert_allclose(dU1.cpu().numpy(), dUo, atol=5e-9, rtol=1e-3)
+    np.testing.assert_allclose(dI1.cpu().numpy(), dIo, atol=5e-9, rtol=1e-3)
+    # and close to the exact-f32 kernel
+    l0, dU0, dI0 = inbatch_loss_and_grads(t(U), t(I), precision=0)
+    scale = dU0.abs().max().item()
+    assert (dU1 - dU0).abs().max().item() < 2e-4 * scale
