@@ -146,6 +146,9 @@ int rihip_ip_index_is_ivf(void* handle);
 int rihip_ip_index_max_k(void);
 int rihip_ip_index_train_ivf(void* handle, int nlist, int n_iter, uint64_t seed, void* stream);
 int rihip_ip_index_set_nprobe(void* handle, int nprobe);
+/* flat indexes with N > 65536: 1 (default) = bf16-MFMA filter with a rigorous error bound + exact f32 re-score of
+ * the survivors (results identical to the all-f32 search, proven per query, exact fallback otherwise); 0 = all-f32 */
+int rihip_ip_index_set_two_precision(void* handle, int enable);
 int rihip_ip_index_search(void* handle, const float* Q, int64_t nq, int k, float* out_scores, int64_t* out_rows,
                           void* stream);
 int rihip_ip_index_save(void* handle, const char* path);          /* host path; synchronous */

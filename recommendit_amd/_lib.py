@@ -63,6 +63,7 @@ SIGNATURES = {
     "rihip_ip_index_max_k": (C.c_int, []),
     "rihip_ip_index_train_ivf": (C.c_int, [vp, C.c_int, C.c_int, C.c_uint64, vp]),
     "rihip_ip_index_set_nprobe": (C.c_int, [vp, C.c_int]),
+    "rihip_ip_index_set_two_precision": (C.c_int, [vp, C.c_int]),
     "rihip_ip_index_search": (C.c_int, [vp, vp, c_i64, C.c_int, vp, vp, vp]),
     "rihip_ip_index_save": (C.c_int, [vp, C.c_char_p]),
     "rihip_ip_index_load": (C.c_int, [C.c_char_p, C.POINTER(vp)]),

@@ -46,6 +46,7 @@ __device__ __forceinline__ uint64_t make_key(float s, uint32_t row) {
 
 struct ScanArgs {
   const float* X;        // corpus [N,d] (list-ordered for IVF)
+  const void* Xb;        // bf16 copy of the corpus [N,d] (filter pass of the two-precision search), or null
   int64_t n_virtual;     // virtual rows scanned: row(i) = i * row_stride
   int64_t row_stride;
   const float* Q;        // [nq,d]
@@ -224,6 +225,195 @@ __global__ __launch_bounds__(256) void ivf_block_tiles_kernel(const uint32_t* __
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Two-precision exact search for large corpora: FILTER on plain-bf16 MFMA (16x fewer matrix cycles than exact
+// f32), then RE-SCORE the few survivors in exact f32.  |s - s_bf16| <= (2^-8 + 2^-18) |q| |x| (each operand
+// rounded to bf16 with relative error <= 2^-9), so rows outside the candidate set {s_bf16 >= thr} have exact
+// score < thr + eps; if the k-th exact score of the candidates is >= thr + eps the top-k is proven complete,
+// otherwise the query takes the exact-f32 fallback.  Results are therefore bit-identical to the all-f32 search.
+// ---------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+__global__ void to_bf16_kernel(const float* __restrict__ x, int64_t n, __bf16* __restrict__ y) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+    y[i] = (__bf16)v.x; y[i + 1] = (__bf16)v.y; y[i + 2] = (__bf16)v.z; y[i + 3] = (__bf16)v.w;
+  } else {
+    for (int64_t j = i; j < n; ++j) y[j] = (__bf16)x[j];
+  }
+}
+// max over rows of |x_row|^2 (order-independent: max of non-negative floats via int atomicMax)
+__global__ __launch_bounds__(256) void rownorm_max_kernel(const float* __restrict__ X, int64_t N, int d, int* out_bits) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float best = 0.f;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < N; row += (int64_t)gridDim.x * 4) {
+    float s = 0.f;
+    for (int k = lane; k < d; k += 64) { const float v = X[row * d + k]; s += v * v; }
+    s = wave_sum(s);
+    best = fmaxf(best, s);
+  }
+  if (lane == 0) atomicMax(out_bits, __float_as_int(best));
+}
+
+constexpr int QBB = 256;  // queries per workgroup of the bf16 filter (64 per wave: two 32-query groups)
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void scan_bf16_kernel(ScanArgs a) {
+  constexpr int LDB = D + 8, KB = D / 16;
+  constexpr int NV = (TRS * (D / 8) + 255) / 256;  // 16-byte pieces staged per thread per tile
+  __shared__ __attribute__((aligned(16))) __bf16 Xs[3][TRS * LDB];
+  const __bf16* Xb = reinterpret_cast<const __bf16*>(a.Xb);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r31 = lane & 31, hh = lane >> 5;
+  int64_t q[2];
+  bool q_ok[2];
+  float thr[2];
+  uint64_t* my_cand[2];
+  bf16x8_t qf[2][KB];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    q[g] = (int64_t)blockIdx.x * QBB + w * 64 + g * 32 + r31;
+    q_ok[g] = q[g] < a.nq;
+    const int64_t qrow = q_ok[g] ? q[g] : (a.nq - 1);
+    thr[g] = (a.thr && q_ok[g]) ? a.thr[q[g]] : -INFINITY;
+    my_cand[g] = a.cand + (size_t)qrow * a.cap;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(&a.Q[qrow * D + kb * 16 + 8 * hh]);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(&a.Q[qrow * D + kb * 16 + 8 * hh + 4]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { qf[g][kb][j] = (__bf16)v0[j]; qf[g][kb][4 + j] = (__bf16)v1[j]; }
+    }
+  }
+  const int64_t n_seq = (a.n_virtual + TRS - 1) / TRS;
+  const int64_t per = (n_seq + a.nsplit - 1) / a.nsplit;
+  const int64_t i0 = (int64_t)blockIdx.y * per;
+  const int64_t i1 = (i0 + per < n_seq) ? i0 + per : n_seq;
+  if (i0 >= i1) return;
+
+  bf16x8_t stage[NV];
+  auto load_tile = [&](int64_t tile) {
+    const int64_t v_base = tile * TRS;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * 256;
+      const int r = idx / (D / 8), c8 = idx % (D / 8);
+      const int64_t v = v_base + r;
+      bf16x8_t val;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) val[j] = (__bf16)0.f;
+      if (idx < TRS * (D / 8) && v < a.n_virtual)
+        val = *reinterpret_cast<const bf16x8_t*>(Xb + (size_t)(v * a.row_stride) * D + c8 * 8);
+      stage[i] = val;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * 256;
+      const int r = idx / (D / 8), c8 = idx % (D / 8);
+      if (idx < TRS * (D / 8)) *reinterpret_cast<bf16x8_t*>(&Xs[buf][r * LDB + c8 * 8]) = stage[i];
+    }
+  };
+  auto emit = [&](const f32x16& acc, int64_t tile, int g) {
+    const int64_t v_base = tile * TRS;
+    if (!q_ok[g]) return;
+    if (a.dense) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t v = v_base + acc_row(r, lane);
+        if (v < a.n_virtual) my_cand[g][v] = make_key(acc[r], (uint32_t)v);
+      }
+      return;
+    }
+    unsigned hits = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t v = v_base + acc_row(r, lane);
+      if (v < a.n_virtual && acc[r] >= thr[g]) hits |= (1u << r);
+    }
+    if (hits) {
+      int pos = atomicAdd(&a.count[q[g]], __popc(hits));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (hits & (1u << r)) {
+          const int64_t v = v_base + acc_row(r, lane);
+          if (pos < a.cap) my_cand[g][pos] = make_key(acc[r], (uint32_t)v);
+          ++pos;
+        }
+      }
+    }
+  };
+  auto s_chain = [&](const __bf16* Xt, f32x16& a0, f32x16& a1) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(&Xt[r31 * LDB + kb * 16 + 8 * hh]);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, qf[0][kb], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, qf[1][kb], a1, 0, 0, 0);
+    }
+  };
+
+  load_tile(i0);
+  store_tile(0);
+  if (i0 + 1 < i1) {
+    load_tile(i0 + 1);
+    store_tile(1);
+  }
+  __syncthreads();
+  f32x16 st0 = zero16(), st1 = zero16();
+  s_chain(Xs[0], st0, st1);
+#pragma unroll 1
+  for (int64_t i = i0; i < i1; ++i) {
+    const int it = (int)((i - i0) % 3);
+    const int nxt = (it + 1) % 3, pre = (it + 2) % 3;
+    const bool has_next = (i + 1 < i1), has_pre = (i + 2 < i1);
+    if (has_pre) load_tile(i + 2);
+    f32x16 sn0 = zero16(), sn1 = zero16();
+    if (has_next) s_chain(Xs[nxt], sn0, sn1);
+    emit(st0, i, 0);
+    emit(st1, i, 1);
+    if (has_pre) store_tile(pre);
+    st0 = sn0;
+    st1 = sn1;
+    __syncthreads();
+  }
+}
+
+// exact f32 re-score of the survivors: 16 lanes per candidate, fixed summation order
+template <int D>
+__global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ X, const float* __restrict__ Q,
+                                                     uint64_t* cand, int64_t cap, const int* __restrict__ count,
+                                                     float* qnorm) {
+  constexpr int PER = D / 16;  // floats per lane
+  const int64_t q = blockIdx.x;
+  const int tid = threadIdx.x, l16 = tid & 15, grp = tid >> 4;
+  float qv[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) qv[j] = Q[q * D + l16 * PER + j];
+  {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) s += qv[j] * qv[j];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (tid == 0) qnorm[q] = sqrtf(s);
+  }
+  const int cnt = count[q];
+  const int64_t n = cnt < cap ? cnt : cap;
+  uint64_t* keys = cand + (size_t)q * cap;
+  for (int64_t i = grp; i < n; i += 16) {
+    const uint64_t key = keys[i];
+    const uint32_t row = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) s = fmaf(qv[j], X[(size_t)row * D + l16 * PER + j], s);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (l16 == 0) keys[i] = make_key(s, row);
+  }
+}
+
 // ---- finalize: radix-select the k_sel best keys of query q, sort them, emit -------------------
 struct FinArgs {
   const uint64_t* cand;  // [nq, cap]
@@ -241,6 +431,11 @@ struct FinArgs {
   float* thr_out;        // mode 1
   int* fail_flags;       // [nq] mode 0: 1 if count<need_min or count>cap
   int64_t need_min;      // min(k, N_effective): candidates required for exactness (0 => no check)
+  // two-precision search: candidates were filtered by APPROXIMATE scores >= thr_chk[q]; the exact top-k is
+  // proven complete iff its k-th exact score >= thr_chk[q] + eps_scale*qnorm[q] + 2e-6
+  const float* thr_chk;
+  const float* qnorm;
+  float eps_scale;
 };
 
 __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
@@ -255,10 +450,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
   const uint64_t* keys = a.cand + (size_t)q * a.cap;
   const int64_t oslot = a.out_slot ? a.out_slot[qi] : qi;
 
-  if (a.mode == 0 && a.fail_flags) {
-    const bool fail = (cnt_raw > a.cap) || (a.need_min > 0 && cnt_raw < a.need_min);
-    if (tid == 0) a.fail_flags[q] = fail ? 1 : 0;
-  }
+  bool fail = (cnt_raw > a.cap) || (a.need_min > 0 && cnt_raw < a.need_min);
   int k_sel = (a.mode == 0) ? a.k : a.rank;
   if (k_sel > n) k_sel = (int)n;
 
@@ -344,6 +536,11 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
       __syncthreads();
     }
   }
+  if (a.thr_chk && k_sel == a.k && k_sel > 0) {  // completeness proof of the approximate filter
+    const float sk = ord2f((uint32_t)(sbuf[k_sel - 1] >> 32));
+    if (sk < a.thr_chk[q] + a.eps_scale * a.qnorm[q] + 2e-6f) fail = true;
+  }
+  if (a.fail_flags && tid == 0) a.fail_flags[q] = fail ? 1 : 0;
   for (int i = tid; i < a.k; i += 256) {
     float sc = -INFINITY;
     int64_t row = -1;
@@ -500,6 +697,10 @@ struct IpIndex {
   int d = 0;
   int64_t N = 0;         // real vectors
   float* X = nullptr;    // brute force: [N,d]; IVF: [Np,d] list-ordered, zero-padded to 64-row tiles
+  __bf16* Xb = nullptr;  // bf16 copy of X for the filter pass (flat index, N > 4*SAMPLE)
+  float max_norm = 0.f;  // max row 2-norm (error bound of the bf16 filter)
+  int two_precision = 1; // 1: bf16 filter + exact f32 re-score; 0: all-f32 search
+  DevBuf<float> qnorm;
   // IVF
   int nlist = 0, nprobe = 1;
   bool ivf = false;
@@ -521,8 +722,8 @@ struct IpIndex {
 #define RCCHK(e) do { int _rc = (e); if (_rc) return _rc; } while (0)
 
 void free_index_arrays(IpIndex* h) {
-  hipFree(h->X); hipFree(h->C); hipFree(h->tile_list); hipFree(h->row_ids);
-  h->X = nullptr; h->C = nullptr; h->tile_list = nullptr; h->row_ids = nullptr;
+  hipFree(h->X); hipFree(h->C); hipFree(h->tile_list); hipFree(h->row_ids); hipFree(h->Xb);
+  h->X = nullptr; h->C = nullptr; h->tile_list = nullptr; h->row_ids = nullptr; h->Xb = nullptr;
   h->N = 0; h->Np = 0; h->ivf = false; h->list_len.clear();
 }
 
@@ -617,27 +818,56 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
   }
 
   // ---- pass 0: threshold from a strided sample
+  const bool two_prec = h->two_precision && h->Xb != nullptr;
   const int64_t stride = h->N / SAMPLE;
   const int64_t S = (h->N + stride - 1) / stride;  // virtual rows i*stride < N
   const double m = (double)k * (double)S / (double)h->N;
-  const int rank = (int)ceil(m + 4.0 * sqrt(m) + 4.0);
+  // rank of the sample score used as threshold; the two-precision filter needs a little more head-room because
+  // the completeness proof asks for s_k >= thr + eps
+  const int rank = (int)ceil((m + 4.0 * sqrt(m) + 4.0) * (two_prec ? 1.5 : 1.0));
   const double expect = (double)rank * (double)h->N / (double)S;
   int64_t cap = 4096;
   while ((double)cap < 2.5 * expect) cap <<= 1;
   if (cap > h->N) cap = h->N;
   RCCHK(h->scand.reserve(nq * S));
   RCCHK(h->cand.reserve(nq * cap));
+  const unsigned qgrid_b = (unsigned)((nq + QBB - 1) / QBB);
+  auto run_scan = [&](const ScanArgs& args, int64_t tiles) -> int {
+    ScanArgs x = args;
+    if (two_prec) {
+      x.Xb = h->Xb;
+      const int64_t qblocks = qgrid_b;
+      int64_t ns = (2 * RIHIP_NCU + qblocks - 1) / qblocks;
+      if (ns > tiles) ns = tiles;
+      if (ns < 1) ns = 1;
+      if (ns > 65535) ns = 65535;
+      x.nsplit = (int)ns;
+      const dim3 grid(qgrid_b, (unsigned)x.nsplit);
+      if (d == 32) hipLaunchKernelGGL((scan_bf16_kernel<32>), grid, dim3(256), 0, st, x);
+      else if (d == 64) hipLaunchKernelGGL((scan_bf16_kernel<64>), grid, dim3(256), 0, st, x);
+      else hipLaunchKernelGGL((scan_bf16_kernel<128>), grid, dim3(256), 0, st, x);
+      return check_launch("scan_bf16");
+    }
+    x.nsplit = pick_nsplit(nq, tiles);
+    return dispatch_scan(d, x, dim3(qgrid, x.nsplit), st);
+  };
   hipLaunchKernelGGL(fill_int_kernel, dim3(nqb), dim3(256), 0, st, h->count.p, nq, (int)S);
   sa.n_virtual = S; sa.row_stride = stride; sa.thr = nullptr; sa.cand = h->scand.p; sa.cap = S; sa.dense = 1;
-  sa.nsplit = pick_nsplit(nq, (S + TRS - 1) / TRS);
-  RCCHK(dispatch_scan(d, sa, dim3(qgrid, sa.nsplit), st));
+  RCCHK(run_scan(sa, (S + TRS - 1) / TRS));
   fa.cand = h->scand.p; fa.cap = S; fa.mode = 1; fa.rank = rank; fa.thr_out = h->thr.p;
   hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3(256), 0, st, fa);
   // ---- pass 1: thresholded scan (atomic append of the rare survivors)
   hipLaunchKernelGGL(fill_int_kernel, dim3(nqb), dim3(256), 0, st, h->count.p, nq, 0);
   sa.n_virtual = h->N; sa.row_stride = 1; sa.thr = h->thr.p; sa.cand = h->cand.p; sa.cap = cap; sa.dense = 0;
-  sa.nsplit = pick_nsplit(nq, n_tiles);
-  RCCHK(dispatch_scan(d, sa, dim3(qgrid, sa.nsplit), st));
+  RCCHK(run_scan(sa, n_tiles));
+  if (two_prec) {  // exact f32 re-score of the survivors (keys rewritten in place)
+    RCCHK(h->qnorm.reserve(nq));
+    if (d == 32) hipLaunchKernelGGL((rerank_kernel<32>), dim3((unsigned)nq), dim3(256), 0, st, h->X, Q, h->cand.p, cap, h->count.p, h->qnorm.p);
+    else if (d == 64) hipLaunchKernelGGL((rerank_kernel<64>), dim3((unsigned)nq), dim3(256), 0, st, h->X, Q, h->cand.p, cap, h->count.p, h->qnorm.p);
+    else hipLaunchKernelGGL((rerank_kernel<128>), dim3((unsigned)nq), dim3(256), 0, st, h->X, Q, h->cand.p, cap, h->count.p, h->qnorm.p);
+    fa.thr_chk = h->thr.p; fa.qnorm = h->qnorm.p;
+    fa.eps_scale = (float)((1.0 / 256.0 + 1.0 / 262144.0) * (double)h->max_norm * 1.001);
+  }
   // ---- pass 2: finalize + exactness flags
   fa.cand = h->cand.p; fa.cap = cap; fa.mode = 0; fa.fail_flags = h->fail_flags.p;
   fa.need_min = k < h->N ? k : h->N; fa.thr_out = nullptr;
@@ -691,7 +921,7 @@ extern "C" int rihip_ip_index_destroy(void* handle) {
   free_index_arrays(h);
   h->cand.release(); h->scand.release(); h->fcand.release(); h->count.release(); h->fail_flags.release();
   h->fail_list.release(); h->n_fail.release(); h->fcount.release(); h->thr.release(); h->fQ.release();
-  h->probe_bits.release(); h->blk_tiles.release(); h->blk_ntiles.release();
+  h->probe_bits.release(); h->blk_tiles.release(); h->blk_ntiles.release(); h->qnorm.release();
   if (h->h_nfail) hipHostFree(h->h_nfail);
   delete h;
   return RIHIP_OK;
@@ -707,6 +937,30 @@ extern "C" int rihip_ip_index_set_vectors(void* handle, const float* X, int64_t 
                         (hipStream_t)stream));
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   h->N = N;
+  if (N > 4 * (int64_t)SAMPLE) {  // two-precision search: bf16 filter copy + the row-norm bound it needs
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = N * h->d;
+    HIPCHK(hipMalloc((void**)&h->Xb, sizeof(__bf16) * (size_t)n));
+    hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, st, h->X, n, h->Xb);
+    int* bits = nullptr;
+    HIPCHK(hipMalloc((void**)&bits, sizeof(int)));
+    HIPCHK(hipMemsetAsync(bits, 0, sizeof(int), st));
+    hipLaunchKernelGGL(rownorm_max_kernel, dim3(1024), dim3(256), 0, st, h->X, N, h->d, bits);
+    int hb = 0;
+    HIPCHK(hipMemcpyAsync(&hb, bits, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    hipFree(bits);
+    float sq;
+    memcpy(&sq, &hb, sizeof(float));
+    h->max_norm = sqrtf(sq);
+  }
+  return RIHIP_OK;
+}
+
+extern "C" int rihip_ip_index_set_two_precision(void* handle, int enable) {
+  IpIndex* h = (IpIndex*)handle;
+  RIHIP_REQUIRE(h, RIHIP_ERR_ARG, "ip_index_set_two_precision: null handle");
+  h->two_precision = enable ? 1 : 0;
   return RIHIP_OK;
 }
 

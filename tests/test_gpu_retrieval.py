@@ -202,3 +202,24 @@ def test_ivf_full_probe_equals_exact_and_recall():
     valid = rows10 >= 0
     S = Q.astype(np.float64) @ X.astype(np.float64).T
     np.testing.assert_allclose(sc10[valid], np.take_along_axis(S, np.where(valid, rows10, 0), 1)[valid], atol=TOL)
+
+
+def test_two_precision_search_equals_all_f32():
+    """bf16-MFMA filter + exact f32 re-score must return the same rows as the all-f32 search (completeness is proven
+    per query; unproven queries take the exact fallback)."""
+    from recommendit_amd import FAISSIndex, _lib
+    rng = np.random.RandomState(11)
+    N, d, nq, k = 250000, 128, 200, 500
+    X, Q = fx.unit_rows(rng, N, d), fx.unit_rows(rng, nq, d)
+    Q[:5] = X[:5]                                  # exact self-matches (score 1.0 on the boundary of the range)
+    idx = FAISSIndex(embed_dim=d, exact=True)
+    idx.build_ivf_index(X, list(range(N)))
+    s2, r2 = idx.batch_search(Q, k=k)              # default: two-precision
+    _lib.check(_lib.lib().rihip_ip_index_set_two_precision(idx.index._h, 0))
+    s1, r1 = idx.batch_search(Q, k=k)              # all-f32
+    _check_topk(s2, r2, Q, X, k)
+    np.testing.assert_allclose(s2, s1, atol=1e-6, rtol=0)
+    same = (r1 == r2).mean()
+    assert same > 0.999, same                      # identical up to f32 near-ties re-ordered by summation order
+    for q in range(nq):
+        assert set(r1[q]) == set(r2[q]) or np.abs(s1[q, -1] - s1[q, -2]) < 1e-6
