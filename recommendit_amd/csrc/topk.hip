@@ -136,22 +136,18 @@ __global__ __launch_bounds__(256, 2) void scan_kernel(ScanArgs a) {
       const int L = a.tile_list[tile >> 1];
       if (!((my_bits[L >> 5] >> (L & 31)) & 1u)) return;
     }
-    unsigned hits = 0;  // per-lane aggregation: one atomic per (query, tile) that has survivors
+    const int n_ok = (a.n_virtual - v_base) < TRS ? (int)(a.n_virtual - v_base) : TRS;
+    // wave-wide vote per accumulator register (a survivor is rare per lane, not per wave)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int64_t v = v_base + acc_row(r, lane);
-      if (v < a.n_virtual && acc[r] >= thr) hits |= (1u << r);
-    }
-    if (hits) {
-      int pos = atomicAdd(&a.count[q], __popc(hits));
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (hits & (1u << r)) {
+      const bool hit = (acc[r] >= thr) && (acc_row(r, lane) < n_ok);
+      if (__any(hit)) {
+        if (hit) {
           const int64_t v = v_base + acc_row(r, lane);
           const int64_t rid = a.row_ids ? a.row_ids[v] : v;
+          const int pos = atomicAdd(&a.count[q], 1);
           // padding rows (rid<0) keep their slot with the lowest key so counts stay consistent
           if (pos < a.cap) my_cand[pos] = (rid >= 0) ? make_key(acc[r], (uint32_t)rid) : 0ull;
-          ++pos;
         }
       }
     }
@@ -258,43 +254,51 @@ __global__ __launch_bounds__(256) void rownorm_max_kernel(const float* __restric
 
 constexpr int QBB = 256;  // queries per workgroup of the bf16 filter (64 per wave: two 32-query groups)
 
-template <int D>
+constexpr int TRB = 64;     // corpus rows per pipeline stage of the bf16 filter (two 32-row MFMA sub-tiles)
+constexpr int QCAP = 1024;  // survivor queue entries per workgroup (LDS)
+
+// DENSE=false: survivors (score >= thr[q]) are queued in LDS and flushed to the per-query candidate lists now and then,
+// so the hot loop contains no global store/atomic (those make hipcc drain the in-flight prefetch with vmcnt(0)).
+// DENSE=true: every score is stored at slot = virtual row (threshold-sample pass).
+template <int D, bool DENSE>
 __global__ __launch_bounds__(256, 2) void scan_bf16_kernel(ScanArgs a) {
   constexpr int LDB = D + 8, KB = D / 16;
-  constexpr int NV = (TRS * (D / 8) + 255) / 256;  // 16-byte pieces staged per thread per tile
-  __shared__ __attribute__((aligned(16))) __bf16 Xs[3][TRS * LDB];
+  constexpr int NV = (TRB * (D / 8) + 255) / 256;  // 16-byte pieces staged per thread per stage
+  __shared__ __attribute__((aligned(16))) __bf16 Xs[3][TRB * LDB];
+  __shared__ uint64_t qkeys[DENSE ? 1 : QCAP];
+  __shared__ unsigned short qidx[DENSE ? 1 : QCAP];
+  __shared__ unsigned q_cnt, q_ovf;
   const __bf16* Xb = reinterpret_cast<const __bf16*>(a.Xb);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r31 = lane & 31, hh = lane >> 5;
-  int64_t q[2];
-  bool q_ok[2];
-  float thr[2];
-  uint64_t* my_cand[2];
-  bf16x8_t qf[2][KB];
+  const int64_t qb0 = (int64_t)blockIdx.x * QBB;
+  const int ql0 = w * 64 + r31, ql1 = ql0 + 32;  // block-local query index of this lane's two query groups
+  const bool ok0 = qb0 + ql0 < a.nq, ok1 = qb0 + ql1 < a.nq;
+  const int64_t qr0 = ok0 ? qb0 + ql0 : a.nq - 1, qr1 = ok1 ? qb0 + ql1 : a.nq - 1;
+  const float th0 = (a.thr && ok0) ? a.thr[qr0] : -INFINITY, th1 = (a.thr && ok1) ? a.thr[qr1] : -INFINITY;
+  bf16x8_t qf0[KB], qf1[KB];
 #pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    q[g] = (int64_t)blockIdx.x * QBB + w * 64 + g * 32 + r31;
-    q_ok[g] = q[g] < a.nq;
-    const int64_t qrow = q_ok[g] ? q[g] : (a.nq - 1);
-    thr[g] = (a.thr && q_ok[g]) ? a.thr[q[g]] : -INFINITY;
-    my_cand[g] = a.cand + (size_t)qrow * a.cap;
+  for (int kb = 0; kb < KB; ++kb) {
+    const f32x4 u0 = *reinterpret_cast<const f32x4*>(&a.Q[qr0 * D + kb * 16 + 8 * hh]);
+    const f32x4 u1 = *reinterpret_cast<const f32x4*>(&a.Q[qr0 * D + kb * 16 + 8 * hh + 4]);
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(&a.Q[qr1 * D + kb * 16 + 8 * hh]);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(&a.Q[qr1 * D + kb * 16 + 8 * hh + 4]);
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(&a.Q[qrow * D + kb * 16 + 8 * hh]);
-      const f32x4 v1 = *reinterpret_cast<const f32x4*>(&a.Q[qrow * D + kb * 16 + 8 * hh + 4]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { qf[g][kb][j] = (__bf16)v0[j]; qf[g][kb][4 + j] = (__bf16)v1[j]; }
+    for (int j = 0; j < 4; ++j) {
+      qf0[kb][j] = (__bf16)u0[j]; qf0[kb][4 + j] = (__bf16)u1[j];
+      qf1[kb][j] = (__bf16)v0[j]; qf1[kb][4 + j] = (__bf16)v1[j];
     }
   }
-  const int64_t n_seq = (a.n_virtual + TRS - 1) / TRS;
+  const int64_t n_seq = (a.n_virtual + TRB - 1) / TRB;
   const int64_t per = (n_seq + a.nsplit - 1) / a.nsplit;
   const int64_t i0 = (int64_t)blockIdx.y * per;
   const int64_t i1 = (i0 + per < n_seq) ? i0 + per : n_seq;
   if (i0 >= i1) return;
+  if (tid == 0) { q_cnt = 0; q_ovf = 0; }
 
   bf16x8_t stage[NV];
   auto load_tile = [&](int64_t tile) {
-    const int64_t v_base = tile * TRS;
+    const int64_t v_base = tile * TRB;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int idx = tid + i * 256;
@@ -303,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void scan_bf16_kernel(ScanArgs a) {
       bf16x8_t val;
 #pragma unroll
       for (int j = 0; j < 8; ++j) val[j] = (__bf16)0.f;
-      if (idx < TRS * (D / 8) && v < a.n_virtual)
+      if (idx < TRB * (D / 8) && v < a.n_virtual)
         val = *reinterpret_cast<const bf16x8_t*>(Xb + (size_t)(v * a.row_stride) * D + c8 * 8);
       stage[i] = val;
     }
@@ -313,44 +317,70 @@ __global__ __launch_bounds__(256, 2) void scan_bf16_kernel(ScanArgs a) {
     for (int i = 0; i < NV; ++i) {
       const int idx = tid + i * 256;
       const int r = idx / (D / 8), c8 = idx % (D / 8);
-      if (idx < TRS * (D / 8)) *reinterpret_cast<bf16x8_t*>(&Xs[buf][r * LDB + c8 * 8]) = stage[i];
+      if (idx < TRB * (D / 8)) *reinterpret_cast<bf16x8_t*>(&Xs[buf][r * LDB + c8 * 8]) = stage[i];
     }
   };
-  auto emit = [&](const f32x16& acc, int64_t tile, int g) {
-    const int64_t v_base = tile * TRS;
-    if (!q_ok[g]) return;
-    if (a.dense) {
+  auto emit = [&](const f32x16& acc, int64_t v_base, int ql, bool ok, float th, int64_t qrow) {
+    if (!ok) return;
+    if (DENSE) {
+      uint64_t* cnd = a.cand + (size_t)qrow * a.cap;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t v = v_base + acc_row(r, lane);
-        if (v < a.n_virtual) my_cand[g][v] = make_key(acc[r], (uint32_t)v);
+        if (v < a.n_virtual) cnd[v] = make_key(acc[r], (uint32_t)v);
       }
       return;
     }
+    float mx = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
+#pragma unroll
+    for (int r = 4; r < 16; r += 4) mx = fmaxf(mx, fmaxf(fmaxf(acc[r], acc[r + 1]), fmaxf(acc[r + 2], acc[r + 3])));
+    if (!(mx >= th)) return;  // no survivor in this 16-score column (the common case)
+    const int n_ok = (a.n_virtual - v_base) < 32 ? (int)(a.n_virtual - v_base) : 32;  // ragged last sub-tile
     unsigned hits = 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int64_t v = v_base + acc_row(r, lane);
-      if (v < a.n_virtual && acc[r] >= thr[g]) hits |= (1u << r);
-    }
+    for (int r = 0; r < 16; ++r)
+      if (acc_row(r, lane) < n_ok && acc[r] >= th) hits |= (1u << r);
     if (hits) {
-      int pos = atomicAdd(&a.count[q[g]], __popc(hits));
+      unsigned pos = atomicAdd(&q_cnt, (unsigned)__popc(hits));  // LDS queue
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         if (hits & (1u << r)) {
-          const int64_t v = v_base + acc_row(r, lane);
-          if (pos < a.cap) my_cand[g][pos] = make_key(acc[r], (uint32_t)v);
+          if (pos < (unsigned)QCAP) {
+            qkeys[pos] = make_key(acc[r], (uint32_t)(v_base + acc_row(r, lane)));
+            qidx[pos] = (unsigned short)ql;
+          } else {
+            q_ovf = 1;
+          }
           ++pos;
         }
       }
     }
   };
-  auto s_chain = [&](const __bf16* Xt, f32x16& a0, f32x16& a1) {
+  auto flush = [&]() {  // all threads; queue -> per-query candidate lists
+    const unsigned n = q_cnt < (unsigned)QCAP ? q_cnt : (unsigned)QCAP;
+    for (unsigned e = tid; e < n; e += 256) {
+      const int64_t qg = qb0 + qidx[e];
+      const int pos = atomicAdd(&a.count[qg], 1);
+      if (pos < a.cap) a.cand[(size_t)qg * a.cap + pos] = qkeys[e];
+    }
+    __syncthreads();
+    if (tid == 0) q_cnt = 0;
+    __syncthreads();
+  };
+  auto compute = [&](int buf, int64_t i) {
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(&Xt[r31 * LDB + kb * 16 + 8 * hh]);
-      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, qf[0][kb], a0, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, qf[1][kb], a1, 0, 0, 0);
+    for (int sub = 0; sub < TRB / 32; ++sub) {
+      const __bf16* Xt = &Xs[buf][sub * 32 * LDB];
+      f32x16 a0 = zero16(), a1 = zero16();
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(&Xt[r31 * LDB + kb * 16 + 8 * hh]);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, qf0[kb], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, qf1[kb], a1, 0, 0, 0);
+      }
+      const int64_t v_base = i * TRB + sub * 32;
+      emit(a0, v_base, ql0, ok0, th0, qr0);
+      emit(a1, v_base, ql1, ok1, th1, qr1);
     }
   };
 
@@ -361,22 +391,22 @@ __global__ __launch_bounds__(256, 2) void scan_bf16_kernel(ScanArgs a) {
     store_tile(1);
   }
   __syncthreads();
-  f32x16 st0 = zero16(), st1 = zero16();
-  s_chain(Xs[0], st0, st1);
 #pragma unroll 1
   for (int64_t i = i0; i < i1; ++i) {
     const int it = (int)((i - i0) % 3);
-    const int nxt = (it + 1) % 3, pre = (it + 2) % 3;
-    const bool has_next = (i + 1 < i1), has_pre = (i + 2 < i1);
-    if (has_pre) load_tile(i + 2);
-    f32x16 sn0 = zero16(), sn1 = zero16();
-    if (has_next) s_chain(Xs[nxt], sn0, sn1);
-    emit(st0, i, 0);
-    emit(st1, i, 1);
-    if (has_pre) store_tile(pre);
-    st0 = sn0;
-    st1 = sn1;
+    if (i + 2 < i1) load_tile(i + 2);
+    compute(it, i);
+    if (i + 2 < i1) store_tile((it + 2) % 3);
     __syncthreads();
+    if (!DENSE && q_cnt >= (unsigned)(QCAP / 2)) flush();  // uniform: q_cnt is read after the barrier
+  }
+  if (!DENSE) {
+    const bool ovf = q_ovf != 0;
+    flush();
+    if (ovf) {  // queue overflowed (adversarial ties): force the exact fallback for this block's queries
+      for (int e = tid; e < QBB; e += 256)
+        if (qb0 + e < a.nq) atomicAdd(&a.count[qb0 + e], 1 << 28);
+    }
   }
 }
 
@@ -843,9 +873,15 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
       if (ns > 65535) ns = 65535;
       x.nsplit = (int)ns;
       const dim3 grid(qgrid_b, (unsigned)x.nsplit);
-      if (d == 32) hipLaunchKernelGGL((scan_bf16_kernel<32>), grid, dim3(256), 0, st, x);
-      else if (d == 64) hipLaunchKernelGGL((scan_bf16_kernel<64>), grid, dim3(256), 0, st, x);
-      else hipLaunchKernelGGL((scan_bf16_kernel<128>), grid, dim3(256), 0, st, x);
+      if (x.dense) {
+        if (d == 32) hipLaunchKernelGGL((scan_bf16_kernel<32, true>), grid, dim3(256), 0, st, x);
+        else if (d == 64) hipLaunchKernelGGL((scan_bf16_kernel<64, true>), grid, dim3(256), 0, st, x);
+        else hipLaunchKernelGGL((scan_bf16_kernel<128, true>), grid, dim3(256), 0, st, x);
+      } else {
+        if (d == 32) hipLaunchKernelGGL((scan_bf16_kernel<32, false>), grid, dim3(256), 0, st, x);
+        else if (d == 64) hipLaunchKernelGGL((scan_bf16_kernel<64, false>), grid, dim3(256), 0, st, x);
+        else hipLaunchKernelGGL((scan_bf16_kernel<128, false>), grid, dim3(256), 0, st, x);
+      }
       return check_launch("scan_bf16");
     }
     x.nsplit = pick_nsplit(nq, tiles);
@@ -853,13 +889,13 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
   };
   hipLaunchKernelGGL(fill_int_kernel, dim3(nqb), dim3(256), 0, st, h->count.p, nq, (int)S);
   sa.n_virtual = S; sa.row_stride = stride; sa.thr = nullptr; sa.cand = h->scand.p; sa.cap = S; sa.dense = 1;
-  RCCHK(run_scan(sa, (S + TRS - 1) / TRS));
+  RCCHK(run_scan(sa, (S + (two_prec ? TRB : TRS) - 1) / (two_prec ? TRB : TRS)));
   fa.cand = h->scand.p; fa.cap = S; fa.mode = 1; fa.rank = rank; fa.thr_out = h->thr.p;
   hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3(256), 0, st, fa);
   // ---- pass 1: thresholded scan (atomic append of the rare survivors)
   hipLaunchKernelGGL(fill_int_kernel, dim3(nqb), dim3(256), 0, st, h->count.p, nq, 0);
   sa.n_virtual = h->N; sa.row_stride = 1; sa.thr = h->thr.p; sa.cand = h->cand.p; sa.cap = cap; sa.dense = 0;
-  RCCHK(run_scan(sa, n_tiles));
+  RCCHK(run_scan(sa, two_prec ? (h->N + TRB - 1) / TRB : n_tiles));
   if (two_prec) {  // exact f32 re-score of the survivors (keys rewritten in place)
     RCCHK(h->qnorm.reserve(nq));
     if (d == 32) hipLaunchKernelGGL((rerank_kernel<32>), dim3((unsigned)nq), dim3(256), 0, st, h->X, Q, h->cand.p, cap, h->count.p, h->qnorm.p);
