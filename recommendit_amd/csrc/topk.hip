@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void rownorm_max_kernel(const float* __restric
 constexpr int QBB = 256;  // queries per workgroup of the bf16 filter (64 per wave: two 32-query groups)
 
 constexpr int TRB = 64;     // corpus rows per pipeline stage of the bf16 filter (two 32-row MFMA sub-tiles)
-constexpr int QCAP = 1024;  // survivor queue entries per workgroup (LDS)
+constexpr int QCOLS = 256;  // survivor queue: 16-score accumulator columns per workgroup (LDS)
 
 // DENSE=false: survivors (score >= thr[q]) are queued in LDS and flushed to the per-query candidate lists now and then,
 // so the hot loop contains no global store/atomic (those make hipcc drain the in-flight prefetch with vmcnt(0)).
@@ -265,8 +265,11 @@ __global__ __launch_bounds__(256, 2) void scan_bf16_kernel(ScanArgs a) {
   constexpr int LDB = D + 8, KB = D / 16;
   constexpr int NV = (TRB * (D / 8) + 255) / 256;  // 16-byte pieces staged per thread per stage
   __shared__ __attribute__((aligned(16))) __bf16 Xs[3][TRB * LDB];
-  __shared__ uint64_t qkeys[DENSE ? 1 : QCAP];
-  __shared__ unsigned short qidx[DENSE ? 1 : QCAP];
+  // A survivor is rare per lane but not per 64-lane wave, so the hot path must stay tiny: a lane whose 16-score
+  // column holds a candidate just dumps the whole column (4 x ds_write_b128 + header) into this queue; thresholding
+  // per element and the global appends happen in flush(), amortised over ~128 columns.
+  __shared__ __attribute__((aligned(16))) float qsc[DENSE ? 1 : QCOLS][16];
+  __shared__ unsigned qhdr[DENSE ? 1 : QCOLS][2];
   __shared__ unsigned q_cnt, q_ovf;
   const __bf16* Xb = reinterpret_cast<const __bf16*>(a.Xb);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -335,33 +338,31 @@ __global__ __launch_bounds__(256, 2) void scan_bf16_kernel(ScanArgs a) {
 #pragma unroll
     for (int r = 4; r < 16; r += 4) mx = fmaxf(mx, fmaxf(fmaxf(acc[r], acc[r + 1]), fmaxf(acc[r + 2], acc[r + 3])));
     if (!(mx >= th)) return;  // no survivor in this 16-score column (the common case)
-    const int n_ok = (a.n_virtual - v_base) < 32 ? (int)(a.n_virtual - v_base) : 32;  // ragged last sub-tile
-    unsigned hits = 0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      if (acc_row(r, lane) < n_ok && acc[r] >= th) hits |= (1u << r);
-    if (hits) {
-      unsigned pos = atomicAdd(&q_cnt, (unsigned)__popc(hits));  // LDS queue
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (hits & (1u << r)) {
-          if (pos < (unsigned)QCAP) {
-            qkeys[pos] = make_key(acc[r], (uint32_t)(v_base + acc_row(r, lane)));
-            qidx[pos] = (unsigned short)ql;
-          } else {
-            q_ovf = 1;
-          }
-          ++pos;
-        }
-      }
+    const unsigned pos = atomicAdd(&q_cnt, 1u);  // LDS
+    if (pos < (unsigned)QCOLS) {
+      f32x4* dst = reinterpret_cast<f32x4*>(qsc[pos]);
+      dst[0] = f32x4{acc[0], acc[1], acc[2], acc[3]};
+      dst[1] = f32x4{acc[4], acc[5], acc[6], acc[7]};
+      dst[2] = f32x4{acc[8], acc[9], acc[10], acc[11]};
+      dst[3] = f32x4{acc[12], acc[13], acc[14], acc[15]};
+      qhdr[pos][0] = (unsigned)ql | ((unsigned)hh << 16);
+      qhdr[pos][1] = (unsigned)v_base;
+    } else {
+      q_ovf = 1;
     }
   };
-  auto flush = [&]() {  // all threads; queue -> per-query candidate lists
-    const unsigned n = q_cnt < (unsigned)QCAP ? q_cnt : (unsigned)QCAP;
-    for (unsigned e = tid; e < n; e += 256) {
-      const int64_t qg = qb0 + qidx[e];
-      const int pos = atomicAdd(&a.count[qg], 1);
-      if (pos < a.cap) a.cand[(size_t)qg * a.cap + pos] = qkeys[e];
+  auto flush = [&]() {  // all threads: queue columns -> per-query candidate lists (16 threads per column)
+    const unsigned n = q_cnt < (unsigned)QCOLS ? q_cnt : (unsigned)QCOLS;
+    for (unsigned e = tid; e < n * 16; e += 256) {
+      const unsigned c = e >> 4, r = e & 15;
+      const unsigned h0 = qhdr[c][0];
+      const int64_t qg = qb0 + (h0 & 0xFFFFu);
+      const int64_t v = (int64_t)qhdr[c][1] + (r & 3) + 8 * (r >> 2) + 4 * (h0 >> 16);
+      const float sc = qsc[c][r];
+      if (v < a.n_virtual && sc >= a.thr[qg]) {
+        const int pos = atomicAdd(&a.count[qg], 1);
+        if (pos < a.cap) a.cand[(size_t)qg * a.cap + pos] = make_key(sc, (uint32_t)v);
+      }
     }
     __syncthreads();
     if (tid == 0) q_cnt = 0;
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void scan_bf16_kernel(ScanArgs a) {
     compute(it, i);
     if (i + 2 < i1) store_tile((it + 2) % 3);
     __syncthreads();
-    if (!DENSE && q_cnt >= (unsigned)(QCAP / 2)) flush();  // uniform: q_cnt is read after the barrier
+    if (!DENSE && q_cnt >= (unsigned)(QCOLS / 2)) flush();  // uniform: q_cnt is read after the barrier
   }
   if (!DENSE) {
     const bool ovf = q_ovf != 0;
@@ -523,7 +524,12 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
       need -= s_above;
       prefix |= (uint64_t)s_bin << shift;
       mask |= 0xFFull << shift;
+      // every key left in the chosen bucket is needed => the remaining low bytes cannot change the selection:
+      // stop (typically after 3-4 of the 8 passes); T = prefix with zero low bytes still satisfies
+      // #{key >= T} == k_sel
+      const bool done = (hist[s_bin] == need);
       __syncthreads();
+      if (done) break;
     }
     T = prefix;
   }
