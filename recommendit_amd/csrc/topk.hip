@@ -137,17 +137,20 @@ __global__ __launch_bounds__(256, 2) void scan_kernel(ScanArgs a) {
       if (!((my_bits[L >> 5] >> (L & 31)) & 1u)) return;
     }
     const int n_ok = (a.n_virtual - v_base) < TRS ? (int)(a.n_virtual - v_base) : TRS;
-    // wave-wide vote per accumulator register (a survivor is rare per lane, not per wave)
+    unsigned hits = 0;  // per-lane aggregation: one atomic per (query, tile) that has survivors
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const bool hit = (acc[r] >= thr) && (acc_row(r, lane) < n_ok);
-      if (__any(hit)) {
-        if (hit) {
+    for (int r = 0; r < 16; ++r)
+      if (acc_row(r, lane) < n_ok && acc[r] >= thr) hits |= (1u << r);
+    if (hits) {
+      int pos = atomicAdd(&a.count[q], __popc(hits));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (hits & (1u << r)) {
           const int64_t v = v_base + acc_row(r, lane);
           const int64_t rid = a.row_ids ? a.row_ids[v] : v;
-          const int pos = atomicAdd(&a.count[q], 1);
           // padding rows (rid<0) keep their slot with the lowest key so counts stay consistent
           if (pos < a.cap) my_cand[pos] = (rid >= 0) ? make_key(acc[r], (uint32_t)rid) : 0ull;
+          ++pos;
         }
       }
     }
