@@ -117,7 +117,7 @@ def cpu_baseline_inbatch(seconds_budget=25.0):
         O.tower_backward(pu, cu, dU)
         O.tower_backward(pi, cp, dI[:blk])
         n_done += blk
-        if time.perf_counter() - t0 > seconds_budget or n_done >= 8 * blk:
+        if time.perf_counter() - t0 > seconds_budget or n_done >= 32 * blk:
             break
     dt = time.perf_counter() - t0
     return {"value": n_done / dt, "unit": "pairs/s", "cores": int(cores), "kind": "port",

@@ -183,6 +183,15 @@ int rihip_rank_features_build(const double* user_tab, int64_t n_user_rows, const
                               int64_t n_item_rows, const int64_t* user_ids, const int64_t* cand_ids, int64_t nq,
                               int kc, const int* col_map, int nf, float* X, void* stream);
 
+/* ---- negative sampler -----------------------------------------------------------------------
+ * Replaces UserItemDataset._sample_negative (src/training/train_embeddings.py:58-63) for a batch: neg_out[i] =
+ * uniform draw from catalog[], re-drawn (up to max_attempts) while users[i]*key_stride + item is in the sorted
+ * array rated_keys[] (one key per rating of any value, :48-50).  Counter-based draws keyed by (seed, i, attempt).
+ * gave_up (device int, nullable) counts samples whose attempts were exhausted. */
+int rihip_sample_negatives(const int64_t* users, int64_t n, const int64_t* catalog, int64_t n_catalog,
+                           const int64_t* rated_keys, int64_t n_rated, int64_t key_stride, uint64_t seed,
+                           int max_attempts, int64_t* neg_out, int* gave_up, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,7 @@ SIGNATURES = {
     "rihip_gbdt_feature_names": (c_i64, [vp, C.c_char_p, c_i64]),
     "rihip_gbdt_feature_importance": (C.c_int, [vp, C.c_int, vp]),
     "rihip_gbdt_predict": (C.c_int, [vp, vp, c_i64, C.c_int, vp, vp]),
+    "rihip_sample_negatives": (C.c_int, [vp, c_i64, vp, c_i64, vp, c_i64, c_i64, C.c_uint64, C.c_int, vp, vp, vp]),
     "rihip_rank_features_widths": (C.c_int, [vp, vp, vp]),
     "rihip_rank_features_build": (C.c_int, [vp, c_i64, vp, c_i64, vp, vp, c_i64, C.c_int, vp, C.c_int, vp, vp]),
 }

@@ -2,8 +2,8 @@
 
 ``UserItemDataset`` keeps the reference constructor and per-sample ``__getitem__`` (:23-79) and
 adds a device-side batch sampler (positives shuffled on the GPU, one rejection-sampled negative per
-positive drawn from the catalogue and rejected while in the user's *rated* set -- :58-63 --, genre
-rows gathered from a device table), because the reference's own DataLoader tops out at ~21 k
+positive drawn by a HIP kernel from the catalogue and rejected while in the user's *rated* set
+-- :58-63 --, genre rows gathered from a device table), because the reference's own DataLoader tops out at ~21 k
 samples/s and would starve the kernels.
 
 ``EmbeddingTrainer`` keeps the reference's constructor arguments and ``train()`` flow (:131-223:
@@ -121,19 +121,18 @@ class UserItemDataset:
         self.d_genres = torch.from_numpy(gm).to(dev)
         self._dev_ready = True
 
-    def sample_negatives(self, users: torch.Tensor, gen: torch.Generator, rounds: int = 24) -> torch.Tensor:
-        """Uniform catalogue draws, re-drawn while the item is in the user's rated set.  `rounds` fixed
-        re-draws (no host sync); the residual acceptance of a rated item is < 0.6^24 even for the
-        heaviest ML-1M user."""
-        n = users.numel()
-        nc = self.d_catalog.numel()
-        neg = self.d_catalog[torch.randint(0, nc, (n,), device=users.device, generator=gen)]
-        for _ in range(rounds):
-            key = users * self.M + neg
-            pos = torch.searchsorted(self.d_rated, key).clamp_(max=self.d_rated.numel() - 1)
-            rej = self.d_rated[pos] == key
-            redraw = self.d_catalog[torch.randint(0, nc, (n,), device=users.device, generator=gen)]
-            neg = torch.where(rej, redraw, neg)
+    def sample_negatives(self, users: torch.Tensor, gen: torch.Generator, max_attempts: int = 1000) -> torch.Tensor:
+        """One HIP launch for the whole batch (rihip_sample_negatives): uniform catalogue draws, re-drawn while the
+        item is in the user's rated set -- the reference's rejection loop (:58-63), bounded at `max_attempts`."""
+        self._prepare_device()
+        u = users.contiguous()
+        neg = torch.empty_like(u)
+        self._neg_calls = getattr(self, "_neg_calls", 0) + 1     # host-side counter: no device sync for the seed
+        seed = (gen.initial_seed() * 0x9E3779B97F4A7C15 + self._neg_calls) & ((1 << 63) - 1)
+        L.check(L.lib().rihip_sample_negatives(u.data_ptr(), u.numel(), self.d_catalog.data_ptr(),
+                                               self.d_catalog.numel(), self.d_rated.data_ptr(), self.d_rated.numel(),
+                                               self.M, seed, max_attempts, neg.data_ptr(), None, L.stream_ptr()),
+                "sample_negatives")
         return neg
 
     def epoch_batches(self, batch_size: int, gen: torch.Generator, with_negatives: bool = True
