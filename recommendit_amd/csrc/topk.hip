@@ -260,6 +260,20 @@ constexpr int QBB = 256;  // queries per workgroup of the bf16 filter (64 per wa
 constexpr int TRB = 64;     // corpus rows per pipeline stage of the bf16 filter (two 32-row MFMA sub-tiles)
 constexpr int QCOLS = 256;  // survivor queue: 16-score accumulator columns per workgroup (LDS)
 
+// queue full (dense survivors): append this column's survivors straight to the query's candidate list.  Kept out of
+// line so that its global atomics/stores do not make hipcc drain the prefetch in the hot loop.
+__device__ __noinline__ void scan_slow_append(const float* col16, float th, int64_t v_base, int hh, int64_t n_virtual,
+                                              int* count_q, uint64_t* cand_q, int64_t cap) {
+  for (int r = 0; r < 16; ++r) {
+    const int64_t v = v_base + (r & 3) + 8 * (r >> 2) + 4 * hh;
+    const float sc = col16[r];
+    if (v < n_virtual && sc >= th) {
+      const int pos = atomicAdd(count_q, 1);
+      if (pos < cap) cand_q[pos] = make_key(sc, (uint32_t)v);
+    }
+  }
+}
+
 // DENSE=false: survivors (score >= thr[q]) are queued in LDS and flushed to the per-query candidate lists now and then,
 // so the hot loop contains no global store/atomic (those make hipcc drain the in-flight prefetch with vmcnt(0)).
 // DENSE=true: every score is stored at slot = virtual row (threshold-sample pass).
@@ -273,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void scan_bf16_kernel(ScanArgs a) {
   // per element and the global appends happen in flush(), amortised over ~128 columns.
   __shared__ __attribute__((aligned(16))) float qsc[DENSE ? 1 : QCOLS][16];
   __shared__ unsigned qhdr[DENSE ? 1 : QCOLS][2];
-  __shared__ unsigned q_cnt, q_ovf;
+  __shared__ unsigned q_cnt;
   const __bf16* Xb = reinterpret_cast<const __bf16*>(a.Xb);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r31 = lane & 31, hh = lane >> 5;
@@ -300,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void scan_bf16_kernel(ScanArgs a) {
   const int64_t i0 = (int64_t)blockIdx.y * per;
   const int64_t i1 = (i0 + per < n_seq) ? i0 + per : n_seq;
   if (i0 >= i1) return;
-  if (tid == 0) { q_cnt = 0; q_ovf = 0; }
+  if (tid == 0) q_cnt = 0;
 
   bf16x8_t stage[NV];
   auto load_tile = [&](int64_t tile) {
@@ -350,8 +364,11 @@ __global__ __launch_bounds__(256, 2) void scan_bf16_kernel(ScanArgs a) {
       dst[3] = f32x4{acc[12], acc[13], acc[14], acc[15]};
       qhdr[pos][0] = (unsigned)ql | ((unsigned)hh << 16);
       qhdr[pos][1] = (unsigned)v_base;
-    } else {
-      q_ovf = 1;
+    } else {  // queue full: rare slow path, still exact
+      float col[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) col[r] = acc[r];
+      scan_slow_append(col, th, v_base, hh, a.n_virtual, &a.count[qrow], a.cand + (size_t)qrow * a.cap, a.cap);
     }
   };
   auto flush = [&]() {  // all threads: queue columns -> per-query candidate lists (16 threads per column)
@@ -404,21 +421,14 @@ __global__ __launch_bounds__(256, 2) void scan_bf16_kernel(ScanArgs a) {
     __syncthreads();
     if (!DENSE && q_cnt >= (unsigned)(QCOLS / 2)) flush();  // uniform: q_cnt is read after the barrier
   }
-  if (!DENSE) {
-    const bool ovf = q_ovf != 0;
-    flush();
-    if (ovf) {  // queue overflowed (adversarial ties): force the exact fallback for this block's queries
-      for (int e = tid; e < QBB; e += 256)
-        if (qb0 + e < a.nq) atomicAdd(&a.count[qb0 + e], 1 << 28);
-    }
-  }
+  if (!DENSE) flush();
 }
 
 // exact f32 re-score of the survivors: 16 lanes per candidate, fixed summation order
 template <int D>
 __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ X, const float* __restrict__ Q,
                                                      uint64_t* cand, int64_t cap, const int* __restrict__ count,
-                                                     float* qnorm) {
+                                                     float* qnorm, int64_t N) {
   constexpr int PER = D / 16;  // floats per lane
   const int64_t q = blockIdx.x;
   const int tid = threadIdx.x, l16 = tid & 15, grp = tid >> 4;
@@ -434,11 +444,12 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ X
     if (tid == 0) qnorm[q] = sqrtf(s);
   }
   const int cnt = count[q];
-  const int64_t n = cnt < cap ? cnt : cap;
+  const int64_t n = cnt <= cap ? cnt : 0;  // overflowed list: the query is re-done exactly anyway
   uint64_t* keys = cand + (size_t)q * cap;
   for (int64_t i = grp; i < n; i += 16) {
     const uint64_t key = keys[i];
     const uint32_t row = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull);
+    if ((int64_t)row >= N) continue;
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < PER; ++j) s = fmaf(qv[j], X[(size_t)row * D + l16 * PER + j], s);
@@ -907,9 +918,9 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
   RCCHK(run_scan(sa, two_prec ? (h->N + TRB - 1) / TRB : n_tiles));
   if (two_prec) {  // exact f32 re-score of the survivors (keys rewritten in place)
     RCCHK(h->qnorm.reserve(nq));
-    if (d == 32) hipLaunchKernelGGL((rerank_kernel<32>), dim3((unsigned)nq), dim3(256), 0, st, h->X, Q, h->cand.p, cap, h->count.p, h->qnorm.p);
-    else if (d == 64) hipLaunchKernelGGL((rerank_kernel<64>), dim3((unsigned)nq), dim3(256), 0, st, h->X, Q, h->cand.p, cap, h->count.p, h->qnorm.p);
-    else hipLaunchKernelGGL((rerank_kernel<128>), dim3((unsigned)nq), dim3(256), 0, st, h->X, Q, h->cand.p, cap, h->count.p, h->qnorm.p);
+    if (d == 32) hipLaunchKernelGGL((rerank_kernel<32>), dim3((unsigned)nq), dim3(256), 0, st, h->X, Q, h->cand.p, cap, h->count.p, h->qnorm.p, h->N);
+    else if (d == 64) hipLaunchKernelGGL((rerank_kernel<64>), dim3((unsigned)nq), dim3(256), 0, st, h->X, Q, h->cand.p, cap, h->count.p, h->qnorm.p, h->N);
+    else hipLaunchKernelGGL((rerank_kernel<128>), dim3((unsigned)nq), dim3(256), 0, st, h->X, Q, h->cand.p, cap, h->count.p, h->qnorm.p, h->N);
     fa.thr_chk = h->thr.p; fa.qnorm = h->qnorm.p;
     fa.eps_scale = (float)((1.0 / 256.0 + 1.0 / 262144.0) * (double)h->max_norm * 1.001);
   }

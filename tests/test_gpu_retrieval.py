@@ -223,3 +223,18 @@ def test_two_precision_search_equals_all_f32():
     assert same > 0.999, same                      # identical up to f32 near-ties re-ordered by summation order
     for q in range(nq):
         assert set(r1[q]) == set(r2[q]) or np.abs(s1[q, -1] - s1[q, -2]) < 1e-6
+
+
+def test_two_precision_dense_survivors_queue_overflow():
+    """Small N / large query batch: ~10 % of the 16-score columns hold a survivor, so the per-workgroup LDS queue
+    overflows into the out-of-line append path (regression: this shape used to fault)."""
+    from recommendit_amd import FAISSIndex
+    rng = np.random.RandomState(12)
+    N, d, nq, k = 100000, 128, 1500, 500
+    X, Q = fx.unit_rows(rng, N, d), fx.unit_rows(rng, nq, d)
+    idx = FAISSIndex(embed_dim=d, exact=True)
+    idx.build_ivf_index(X, list(range(N)))
+    s, r = idx.batch_search(Q, k=k)
+    sel = rng.choice(nq, 24, replace=False)
+    _check_topk(s[sel], r[sel], Q[sel], X, k)
+    assert (np.diff(s, axis=1) <= 0).all() and (r >= 0).all()
