@@ -1,0 +1,90 @@
+"""GPU: edge cases the reference's tests and callers exercise -- empty and single-row batches, k > N, one query,
+ids on the table boundary, repeated ids, status codes instead of aborts."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fixtures as fx
+from oracle import two_tower_np as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(nu=50, ni=60, d=32, H=64, seed=4):
+    from recommendit_amd import TwoTowerModel
+    sd = fx.make_state(nu, ni, d, H, seed)
+    m = TwoTowerModel(nu, ni, embed_dim=d, hidden_dim=H, dropout=0.0)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    return m, sd
+
+
+def test_empty_and_single_row_batches():
+    m, sd = _model()
+    m.eval()
+    with torch.no_grad():
+        e = m.user_tower(torch.zeros((0,), dtype=torch.long))
+        assert e.shape == (0, 32)
+        one = m.item_tower(torch.tensor([60]), torch.ones((1, 18)))
+    assert one.shape == (1, 32) and abs(float(one.norm()) - 1.0) < 1e-5
+    assert m.get_item_embeddings([], np.zeros((0, 18), np.float32)).shape == (0, 32)
+
+
+def test_repeated_and_boundary_ids_gradients():
+    """All samples hit the same two rows (first and last of the table): the dense scatter-add and the row-sparse
+    segment reduce must both sum 257 contributions per row."""
+    from recommendit_amd.trainer import HipBPRTrainer
+    nu, ni, d, H, B = 50, 60, 32, 64, 257
+    m, sd = _model(nu, ni, d, H)
+    m.train()
+    u = np.where(np.arange(B) % 2 == 0, 1, nu).astype(np.int64)
+    p = np.where(np.arange(B) % 2 == 0, ni, 1).astype(np.int64)
+    g = np.zeros((B, 18), np.float32)
+    U = m.user_tower(torch.from_numpy(u).cuda()); P = m.item_tower(torch.from_numpy(p).cuda(), torch.from_numpy(g).cuda())
+    loss = m.in_batch_bpr_loss(U, P)
+    loss.backward()
+    gu = m.user_tower.embedding.weight.grad.cpu().numpy()
+    assert np.abs(gu[2:nu]).max() == 0 and np.abs(gu[0]).max() == 0 and np.abs(gu[1]).max() > 0 and np.abs(gu[nu]).max() > 0
+    pu = O.TowerParams(sd["user_tower.embedding.weight"], sd["user_tower.mlp.0.weight"], sd["user_tower.mlp.0.bias"],
+                       sd["user_tower.mlp.3.weight"], sd["user_tower.mlp.3.bias"])
+    pi = O.TowerParams(sd["item_tower.embedding.weight"], sd["item_tower.mlp.0.weight"], sd["item_tower.mlp.0.bias"],
+                       sd["item_tower.mlp.3.weight"], sd["item_tower.mlp.3.bias"])
+    Uo, cu = O.tower_forward(pu, u); Po, cp = O.tower_forward(pi, p, g)
+    lo, dU, dI = O.in_batch_bpr_loss(Uo, Po)
+    ref = O.embedding_scatter_add(nu + 1, u, O.tower_backward(pu, cu, dU)[0])
+    np.testing.assert_allclose(gu, ref, atol=1e-8, rtol=2e-3)
+    # the sparse path groups the same ids
+    m2, _ = _model(nu, ni, d, H)
+    m2.train()
+    tr = HipBPRTrainer(m2, B, lr=1e-3, loss_mode="inbatch", table_opt="sparse")
+    before = m2.user_tower.embedding.weight.detach().clone()
+    tr.step(torch.from_numpy(u).cuda(), torch.from_numpy(p).cuda(), torch.from_numpy(g).cuda())
+    moved = (m2.user_tower.embedding.weight.detach() - before).abs().sum(1).cpu().numpy()
+    assert moved[1] > 0 and moved[nu] > 0 and moved[2:nu].max() == 0 and moved[0] == 0
+
+
+def test_search_k_larger_than_n_and_single_query():
+    from recommendit_amd import FAISSIndex
+    rng = np.random.RandomState(0)
+    X = fx.unit_rows(rng, 37, 32)
+    idx = FAISSIndex(embed_dim=32, exact=True)
+    idx.build_ivf_index(X, list(range(100, 137)))
+    d, ids = idx.search(X[3] * 7.0, k=500)
+    assert len(ids) == 37 and ids[0] == 103 and abs(d[0] - 1.0) < 1e-6 and (np.diff(d) <= 0).all()
+    s, r = idx.batch_search(X[:1], k=5)
+    assert s.shape == (1, 5) and r[0, 0] == 100
+
+
+def test_status_codes_not_aborts():
+    from recommendit_amd import _lib
+    l = _lib.lib()
+    h = ctypes.c_void_p()
+    assert l.rihip_ip_index_create(48, ctypes.byref(h)) != 0 and b"unsupported" in l.rihip_last_error()
+    assert l.rihip_gbdt_load_text(b"/nonexistent/model.txt", ctypes.byref(h)) != 0 and b"cannot open" in l.rihip_last_error()
+    x = torch.zeros(8, device="cuda")
+    assert l.rihip_adam_dense(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), 8, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0,
+                              None, None) != 0        # step must be >= 1
+    with pytest.raises(RuntimeError, match="no HIP kernel instantiation|unsupported"):
+        from recommendit_amd import TwoTowerModel
+        TwoTowerModel(5, 5, embed_dim=48, hidden_dim=64).user_tower(torch.tensor([1]))

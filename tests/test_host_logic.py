@@ -1,0 +1,107 @@
+"""CPU: host-side logic of the product package (no GPU, no oracle needed except as cross-check)."""
+import math
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from oracle import metrics_np as OM
+from oracle import ranking_features_np as RF
+from oracle import two_tower_np as O
+
+
+def test_cosine_lr_matches_torch_scheduler():
+    from recommendit_amd.trainer import cosine_lr
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=1e-3)
+    sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=10)
+    for e in range(10):
+        assert abs(cosine_lr(1e-3, e, 10) - opt.param_groups[0]["lr"]) < 1e-12
+        assert abs(cosine_lr(1e-3, e, 10) - O.cosine_lr(1e-3, e, 10)) < 1e-15
+        opt.step(); sch.step()
+
+
+def test_metrics_match_oracle_and_reference_known_answers():
+    from recommendit_amd import metrics as M
+    rng = np.random.RandomState(0)
+    for _ in range(50):
+        rec = rng.permutation(30)[:20].tolist()
+        rel = rng.permutation(30)[: rng.randint(0, 6)].tolist()
+        for k in (5, 10, 20):
+            assert M.ndcg_at_k(rec, rel, k) == OM.ndcg_at_k(rec, rel, k)
+            assert M.recall_at_k(rec, rel, k) == OM.recall_at_k(rec, rel, k)
+        assert M.mrr(rec, rel) == OM.mrr(rec, rel)
+    assert abs(M.ndcg_at_k([1, 2, 3, 4, 5], [1, 2, 3], 3) - 1.0) < 1e-12      # reference tests/test_models.py:372-378
+    res = M.evaluate_model({1: [1, 2, 3], 2: [9, 8, 7], 3: [5]}, {1: [1], 2: [7], 3: []}, [1, 3])
+    assert res["n_users"] == 3 and abs(res["ndcg@1"] - 0.5) < 1e-12 and abs(res["mrr"] - (1.0 + 1 / 3) / 2) < 1e-12
+
+
+def test_synthetic_ml1m_shape_and_determinism():
+    from recommendit_amd.synthetic import ml1m_like
+    r1, m1, g1 = ml1m_like(n_users=300, n_item_ids=260, n_catalog=250, n_ratings=20000, seed=3)
+    r2, m2, g2 = ml1m_like(n_users=300, n_item_ids=260, n_catalog=250, n_ratings=20000, seed=3)
+    assert r1.equals(r2) and m1.equals(m2) and np.array_equal(g1, g2)
+    assert r1["user_id"].nunique() == 300 and set(r1["rating"].unique()) <= {1, 2, 3, 4, 5}
+    assert r1.groupby("user_id").size().min() >= 20 and len(m1) == 250 and g1.shape == (261, 18)
+    assert not r1.duplicated(["user_id", "item_id"]).any()
+    assert (r1.groupby("user_id")["timestamp"].apply(lambda s: s.is_monotonic_increasing)).all()
+
+
+def test_dataset_host_path_follows_reference_semantics():
+    from recommendit_amd.synthetic import ml1m_like
+    from recommendit_amd.train_embeddings import UserItemDataset, build_item_genre_dict
+    ratings, movies, gm = ml1m_like(n_users=100, n_item_ids=120, n_catalog=110, n_ratings=5000, seed=1)
+    gd = build_item_genre_dict(movies)
+    assert all(np.array_equal(gd[i], gm[i]) for i in movies["item_id"])
+    ds = UserItemDataset(ratings, gd, sorted(movies["item_id"].tolist()))
+    assert len(ds) == int((ratings["rating"] >= 4).sum())          # train_embeddings.py:43-45
+    rated = ratings.groupby("user_id")["item_id"].apply(set).to_dict()
+    np.random.seed(0)
+    for i in range(0, len(ds), max(1, len(ds) // 40)):
+        u, p, gp, n, gn = ds[i]
+        assert int(n) not in rated[int(u)] and int(n) in gd and int(p) in rated[int(u)]
+        assert gp.shape == (18,) and gp.dtype == torch.float32 and u.dtype == torch.long
+
+
+def test_gpu_feature_store_tables_match_reference_defaults():
+    from recommendit_amd.recommender import GpuFeatureStore, feature_columns
+    st = GpuFeatureStore(3, 4)
+    assert st.user.shape == (4, 24) and st.item.shape == (5, 23)
+    assert st.user[2, :6].tolist() == [3.5, 0.0, 0.5, 0.0, 0.3, 0.3]     # recommender.py:227-232
+    assert st.item[1, :5].tolist() == [3.5, 0.0, 0.0, 0.0, 0.5]          # recommender.py:234-238
+    st.set_user_features(2, {"avg_rating": 4.25, "genre_pref": [0.5] * 3})
+    assert st.user[2, 0] == 4.25 and st.user[2, 6:9].tolist() == [0.5] * 3 and st.user[2, 9] == 0.0
+    st.set_item_features(1, None)
+    assert st.item[1, :5].tolist() == [3.5, 0.0, 0.0, 0.0, 0.5]
+    assert feature_columns() == RF.feature_columns() and len(feature_columns()) == 50
+
+
+def test_checkpoint_keys_and_hidden_dim_inference(tmp_path):
+    from recommendit_amd import TwoTowerModel
+    m = TwoTowerModel(12, 15, embed_dim=32, hidden_dim=64)
+    m.save(str(tmp_path / "m.pt"))
+    ck = torch.load(tmp_path / "m.pt", weights_only=True)
+    assert sorted(ck) == ["embed_dim", "idx_to_item_id", "item_id_to_idx", "n_items", "n_users", "state_dict"]
+    assert "user_tower.mlp.3.weight" in ck["state_dict"] and ck["state_dict"]["item_tower.mlp.0.weight"].shape == (64, 50)
+    m2 = TwoTowerModel.load(str(tmp_path / "m.pt"))
+    assert m2.hidden_dim == 64 and (m2.n_users, m2.n_items, m2.embed_dim) == (12, 15, 32)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v.cpu(), m2.state_dict()[k].cpu())
+
+
+def test_error_conventions_without_backend_calls(tmp_path):
+    from recommendit_amd import FAISSIndex, LightGBMRanker
+    with pytest.raises(RuntimeError, match="Index not built"):
+        FAISSIndex(embed_dim=8).search(np.zeros(8, np.float32))
+    with pytest.raises(RuntimeError, match="Index not built"):
+        FAISSIndex(embed_dim=8).batch_search(np.zeros((1, 8), np.float32))
+    assert FAISSIndex(embed_dim=8).stats() == {"status": "not built"}
+    with pytest.raises(FileNotFoundError):
+        FAISSIndex.load(str(tmp_path / "none.index"))
+    with pytest.raises(RuntimeError, match="not trained"):
+        LightGBMRanker().predict(pd.DataFrame({"a": [1.0]}))
+    with pytest.raises(FileNotFoundError):
+        LightGBMRanker.load(str(tmp_path / "none.lgbm"))
+    assert LightGBMRanker().model_info() == {"status": "not trained"}
+    assert LightGBMRanker().best_iteration == 0 and LightGBMRanker().n_features == 0
