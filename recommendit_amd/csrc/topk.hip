@@ -65,6 +65,7 @@ struct ScanArgs {
   const int* blk_tiles;       // [query blocks, n_scan_tiles] 32-row tiles some query of the block probes
   const int* blk_ntiles;      // [query blocks]
   int64_t n_scan_tiles;
+  int tile_step;              // IVF threshold sample: visit every tile_step-th tile of the block list (0/1 = all)
 };
 
 constexpr int TRS = 32;  // corpus rows per LDS tile of the scan kernel
@@ -92,14 +93,15 @@ __global__ __launch_bounds__(256, 2) void scan_kernel(ScanArgs a) {
   const uint32_t* my_bits = a.probe_bits ? a.probe_bits + (size_t)qrow * a.pb_words : nullptr;
 
   const int* tl = a.blk_tiles ? a.blk_tiles + (size_t)blockIdx.x * a.n_scan_tiles : nullptr;
-  const int64_t n_seq = a.blk_tiles ? (int64_t)a.blk_ntiles[blockIdx.x] : (a.n_virtual + TRS - 1) / TRS;
+  const int tstep = (a.blk_tiles && a.tile_step > 1) ? a.tile_step : 1;
+  const int64_t n_seq = a.blk_tiles ? ((int64_t)a.blk_ntiles[blockIdx.x] + tstep - 1) / tstep : (a.n_virtual + TRS - 1) / TRS;
   const int64_t per = (n_seq + a.nsplit - 1) / a.nsplit;
   const int64_t i0 = (int64_t)blockIdx.y * per;
   const int64_t i1 = (i0 + per < n_seq) ? i0 + per : n_seq;
   if (i0 >= i1) return;  // uniform across the workgroup
 
   f32x4 stage[NV];
-  auto tile_at = [&](int64_t i) -> int64_t { return tl ? (int64_t)tl[i] : i; };
+  auto tile_at = [&](int64_t i) -> int64_t { return tl ? (int64_t)tl[i * tstep] : i; };
   auto load_tile = [&](int64_t tile) {
     const int64_t v_base = tile * TRS;
 #pragma unroll
@@ -481,6 +483,8 @@ struct FinArgs {
   const float* thr_chk;
   const float* qnorm;
   float eps_scale;
+  // IVF with a sampled threshold: fewer than k candidates is only acceptable when nothing was filtered (thr = -inf)
+  const float* ivf_thr;
 };
 
 __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
@@ -496,6 +500,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
   const int64_t oslot = a.out_slot ? a.out_slot[qi] : qi;
 
   bool fail = (cnt_raw > a.cap) || (a.need_min > 0 && cnt_raw < a.need_min);
+  if (a.ivf_thr && cnt_raw < a.k && a.ivf_thr[q] > -INFINITY) fail = true;
   int k_sel = (a.mode == 0) ? a.k : a.rank;
   if (k_sel > n) k_sel = (int)n;
 
@@ -549,7 +554,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
   }
 
   if (a.mode == 1) {
-    if (tid == 0) a.thr_out[q] = (k_sel > 0) ? ord2f((uint32_t)(T >> 32)) : -INFINITY;
+    if (tid == 0) a.thr_out[q] = (k_sel > 0 && k_sel == a.rank) ? ord2f((uint32_t)(T >> 32)) : -INFINITY;
     return;
   }
 
@@ -826,33 +831,88 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
   fa.nq = nq; fa.k = k; fa.count = h->count.p; fa.out_scores = out_s; fa.out_rows = out_r;
 
   if (h->ivf) {
-    // candidates = every vector of the probed lists; upper bound = the nprobe longest lists (padded)
+    // population upper bound of one query = the nprobe longest lists (padded to the 64-row granule)
     std::vector<int64_t> ll = h->list_len;
     std::sort(ll.begin(), ll.end(), [](int64_t x, int64_t y) { return x > y; });
-    int64_t cap = 0;
-    for (int i = 0; i < h->nprobe && i < (int)ll.size(); ++i) cap += (ll[i] + TR - 1) / TR * TR;
-    if (cap < 1) cap = 1;
-    RCCHK(h->cand.reserve(nq * cap));
+    int64_t cap_full = 0;
+    for (int i = 0; i < h->nprobe && i < (int)ll.size(); ++i) cap_full += (ll[i] + TR - 1) / TR * TR;
+    if (cap_full < 1) cap_full = 1;
     const int pbw = (h->nlist + 31) / 32;
-    RCCHK(h->probe_bits.reserve(nq * pbw));
-    hipLaunchKernelGGL(ivf_probe_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), sizeof(float) * 4 * h->nlist, st, Q,
-                       nq, d, h->C, h->nlist, h->nprobe, h->probe_bits.p, pbw);
-    hipLaunchKernelGGL(fill_int_kernel, dim3(nqb), dim3(256), 0, st, h->count.p, nq, 0);
-    sa.n_virtual = Nphys; sa.row_stride = 1; sa.thr = nullptr; sa.cand = h->cand.p; sa.cap = cap; sa.dense = 0;
-    sa.nsplit = pick_nsplit(nq, n_tiles);
-    sa.tile_list = h->tile_list; sa.probe_bits = h->probe_bits.p; sa.pb_words = pbw; sa.row_ids = h->row_ids;
     RIHIP_REQUIRE(pbw <= 64, RIHIP_ERR_SHAPE, "ip_index: nlist=%d > 2048 unsupported", h->nlist);
     const int64_t n_scan_tiles = (Nphys + TRS - 1) / TRS;
-    RCCHK(h->blk_tiles.reserve((int64_t)qgrid * n_scan_tiles));
-    RCCHK(h->blk_ntiles.reserve(qgrid));
-    hipLaunchKernelGGL(ivf_block_tiles_kernel, dim3(qgrid), dim3(256), 0, st, h->probe_bits.p, pbw, nq, h->tile_list,
-                       n_scan_tiles, h->blk_tiles.p, h->blk_ntiles.p);
-    sa.blk_tiles = h->blk_tiles.p; sa.blk_ntiles = h->blk_ntiles.p; sa.n_scan_tiles = n_scan_tiles;
-    sa.nsplit = pick_nsplit(nq, (n_scan_tiles * h->nprobe) / (h->nlist > 0 ? h->nlist : 1) + 1);
-    RCCHK(dispatch_scan(d, sa, dim3(qgrid, sa.nsplit), st));
-    fa.cand = h->cand.p; fa.cap = cap; fa.mode = 0;
+    // one IVF pass over `n` queries: probe -> block tile lists -> scan (optionally thresholded / tile-sampled)
+    auto ivf_scan = [&](const float* Qp, int64_t n, const float* thr, uint64_t* cand, int64_t cap, int tile_step) -> int {
+      const unsigned qg = (unsigned)((n + QB - 1) / QB);
+      ScanArgs x;
+      memset(&x, 0, sizeof(x));
+      x.X = h->X; x.Q = Qp; x.nq = n; x.count = h->count.p; x.n_virtual = Nphys; x.row_stride = 1; x.thr = thr;
+      x.cand = cand; x.cap = cap; x.dense = 0; x.tile_list = h->tile_list; x.probe_bits = h->probe_bits.p;
+      x.pb_words = pbw; x.row_ids = h->row_ids; x.blk_tiles = h->blk_tiles.p; x.blk_ntiles = h->blk_ntiles.p;
+      x.n_scan_tiles = n_scan_tiles; x.tile_step = tile_step;
+      const int64_t est = (n_scan_tiles * h->nprobe) / (h->nlist > 0 ? h->nlist : 1) / (tile_step > 1 ? tile_step : 1) + 1;
+      x.nsplit = pick_nsplit(n, est);
+      hipLaunchKernelGGL(fill_int_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->count.p, n, 0);
+      return dispatch_scan(d, x, dim3(qg, x.nsplit), st);
+    };
+    auto ivf_prepare = [&](const float* Qp, int64_t n) -> int {
+      const unsigned qg = (unsigned)((n + QB - 1) / QB);
+      RCCHK(h->probe_bits.reserve(n * pbw));
+      RCCHK(h->blk_tiles.reserve((int64_t)qg * n_scan_tiles));
+      RCCHK(h->blk_ntiles.reserve(qg));
+      hipLaunchKernelGGL(ivf_probe_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), sizeof(float) * 4 * h->nlist, st, Qp,
+                         n, d, h->C, h->nlist, h->nprobe, h->probe_bits.p, pbw);
+      hipLaunchKernelGGL(ivf_block_tiles_kernel, dim3(qg), dim3(256), 0, st, h->probe_bits.p, pbw, n, h->tile_list,
+                         n_scan_tiles, h->blk_tiles.p, h->blk_ntiles.p);
+      return check_launch("ivf prepare");
+    };
+    // unfiltered pass (every probed vector is a candidate): small populations and the exact fallback
+    auto ivf_full = [&](const float* Qp, int64_t n, const int* out_slot) -> int {
+      RCCHK(h->fcand.reserve(n * cap_full));
+      RCCHK(ivf_prepare(Qp, n));
+      RCCHK(ivf_scan(Qp, n, nullptr, h->fcand.p, cap_full, 1));
+      FinArgs f2;
+      memset(&f2, 0, sizeof(f2));
+      f2.nq = n; f2.k = k; f2.count = h->count.p; f2.out_scores = out_s; f2.out_rows = out_r; f2.cand = h->fcand.p;
+      f2.cap = cap_full; f2.mode = 0; f2.out_slot = out_slot;
+      hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)n), dim3(256), 0, st, f2);
+      return check_launch("finalize");
+    };
+    const int SS = 16;  // threshold sample: every 16th probed tile
+    if (cap_full <= 16384 || (double)k * 4.0 > (double)cap_full / SS) return ivf_full(Q, nq, nullptr);
+
+    const double m = (double)k / SS;
+    const int rank = (int)ceil(m + 4.0 * sqrt(m) + 4.0);
+    int64_t cap = 4096;
+    while ((double)cap < 2.5 * rank * SS) cap <<= 1;
+    if (cap > cap_full) cap = cap_full;
+    const int64_t cap_s = cap_full / SS + 2 * TR * h->nprobe + 64;
+    RCCHK(h->scand.reserve(nq * cap_s));
+    RCCHK(h->cand.reserve(nq * cap));
+    RCCHK(ivf_prepare(Q, nq));
+    RCCHK(ivf_scan(Q, nq, nullptr, h->scand.p, cap_s, SS));                      // pass A: sampled tiles, no filter
+    fa.cand = h->scand.p; fa.cap = cap_s; fa.mode = 1; fa.rank = rank; fa.thr_out = h->thr.p;
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3(256), 0, st, fa);
-    return check_launch("finalize");
+    RCCHK(ivf_scan(Q, nq, h->thr.p, h->cand.p, cap, 1));                         // pass B: all probed tiles, filtered
+    fa.cand = h->cand.p; fa.cap = cap; fa.mode = 0; fa.thr_out = nullptr; fa.fail_flags = h->fail_flags.p;
+    fa.ivf_thr = h->thr.p;
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3(256), 0, st, fa);
+    hipLaunchKernelGGL(fill_int_kernel, dim3(1), dim3(64), 0, st, h->n_fail.p, 1, 0);
+    hipLaunchKernelGGL(collect_fail_kernel, dim3(nqb), dim3(256), 0, st, h->fail_flags.p, nq, h->fail_list.p, h->n_fail.p);
+    RCCHK(check_launch("finalize"));
+    HIPCHK(hipMemcpyAsync(h->h_nfail, h->n_fail.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const int nf = *h->h_nfail;
+    if (nf > 0) {  // threshold too aggressive (or candidate overflow) for these queries: unfiltered re-do
+      const int FCH = 64;
+      RCCHK(h->fQ.reserve((int64_t)FCH * d));
+      for (int f0 = 0; f0 < nf; f0 += FCH) {
+        const int nfc = (nf - f0 < FCH) ? nf - f0 : FCH;
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((nfc * d + 255) / 256)), dim3(256), 0, st, Q,
+                           h->fail_list.p + f0, nfc, d, h->fQ.p);
+        RCCHK(ivf_full(h->fQ.p, nfc, h->fail_list.p + f0));
+      }
+    }
+    return RIHIP_OK;
   }
 
   if (h->N <= 4 * (int64_t)SAMPLE) {

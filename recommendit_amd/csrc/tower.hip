@@ -138,7 +138,7 @@ __device__ __forceinline__ void gather_tile(float* Xs, int ldx, const float* __r
 }
 
 template <int D, int H, bool ITEM>
-__global__ __launch_bounds__(256) void tower_fwd_kernel(TowerFwdArgs a) {
+__global__ __launch_bounds__(256, 2) void tower_fwd_kernel(TowerFwdArgs a) {
   constexpr int K1 = D + (ITEM ? 18 : 0);
   constexpr int K1P = (K1 + 7) / 8 * 8;
   constexpr int LDX = K1P + 4, LDH = H + 4, LDY = D + 4;
@@ -534,6 +534,7 @@ extern "C" int rihip_tower_forward(const float* table, int64_t n_rows, const int
                 "tower_forward: unsupported (embed_dim=%d, hidden_dim=%d)", d, hidden);
   RIHIP_REQUIRE(B >= 0 && n_rows > 0, RIHIP_ERR_ARG, "tower_forward: bad sizes B=%lld n_rows=%lld", (long long)B,
                 (long long)n_rows);
+  if (B == 0) return RIHIP_OK;  // empty batch: nothing to read or write
   RIHIP_REQUIRE(table && ids && W1 && b1 && W2 && b2 && out, RIHIP_ERR_ARG, "tower_forward: null pointer");
   RIHIP_REQUIRE(aligned16(table) && aligned16(out) && (!hid || aligned16(hid)), RIHIP_ERR_ARG,
                 "tower_forward: table/out/hid must be 16-byte aligned");
@@ -546,7 +547,7 @@ extern "C" int rihip_tower_forward(const float* table, int64_t n_rows, const int
   a.seed_mul = rihip_seed_mul(seed); a.thresh24 = rihip_thresh24(dropout_p);
   a.scale = 1.f / (1.f - dropout_p); a.row0 = row0; a.err_flag = err_flag;
   const int64_t ntiles = (B + TM - 1) / TM;
-  const int wgs_per_cu = (d >= 128) ? 1 : 2;  // register-limited residency of the forward kernel
+  const int wgs_per_cu = 2;  // the forward kernel is built for 2 workgroups per CU (launch bounds)
   const int grid = (int)(ntiles < wgs_per_cu * RIHIP_NCU ? ntiles : wgs_per_cu * RIHIP_NCU);
   const bool item = genres != nullptr;
   hipStream_t st = (hipStream_t)stream;
@@ -586,6 +587,7 @@ extern "C" int rihip_tower_backward(const float* table, int64_t n_rows, const in
                                     int accumulate, float* workspace, void* stream) {
   RIHIP_REQUIRE(rihip_tower_supported(d, hidden), RIHIP_ERR_SHAPE,
                 "tower_backward: unsupported (embed_dim=%d, hidden_dim=%d)", d, hidden);
+  if (B <= 0) return RIHIP_OK;
   RIHIP_REQUIRE(table && ids && W1 && W2 && grad_out && out && denom && hid && dX && dW1 && db1 && dW2 && db2 &&
                     workspace,
                 RIHIP_ERR_ARG, "tower_backward: null pointer");

@@ -90,6 +90,9 @@ class _TowerFn(torch.autograd.Function):
         B, d = out.shape
         H = W1.shape[0]
         K1 = W1.shape[1]
+        if B == 0:  # empty batch: all gradients are zero
+            z = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=dev)
+            return torch.zeros_like(table), z(H, K1), z(H), z(d, H), z(d), None, None, None, None, None
         gout = gout.to(device=dev, dtype=torch.float32).contiguous()
         dX = torch.empty((B, d), dtype=torch.float32, device=dev)
         dW1 = torch.empty((H, K1), dtype=torch.float32, device=dev)

@@ -238,3 +238,28 @@ def test_two_precision_dense_survivors_queue_overflow():
     sel = rng.choice(nq, 24, replace=False)
     _check_topk(s[sel], r[sel], Q[sel], X, k)
     assert (np.diff(s, axis=1) <= 0).all() and (r >= 0).all()
+
+
+def test_ivf_large_lists_thresholded_path():
+    """Lists large enough for the sampled-threshold IVF scan: with nprobe == nlist the result must be the exact
+    top-k; with nprobe < nlist every returned (score,row) is a true inner product, sorted, k of them, and the
+    batch result equals the one-query-at-a-time result (different blocks / tile lists / thresholds)."""
+    from recommendit_amd import FAISSIndex
+    rng = np.random.RandomState(21)
+    N, d, nq, k = 300000, 64, 150, 100
+    X, Q = fx.unit_rows(rng, N, d), fx.unit_rows(rng, nq, d)
+    ivf = FAISSIndex(embed_dim=d, n_lists=50, n_probe=50)
+    ivf.build_ivf_index(X, list(range(N)), kmeans_iters=5)
+    sc, rows = ivf.batch_search(Q, k=k)
+    _check_topk(sc, rows, Q, X, k)
+    ivf.set_n_probe(5)
+    sc5, rows5 = ivf.batch_search(Q, k=k)
+    assert (rows5 >= 0).all() and (np.diff(sc5, axis=1) <= 0).all()
+    S = Q.astype(np.float64) @ X.astype(np.float64).T
+    np.testing.assert_allclose(sc5, np.take_along_axis(S, rows5, 1), atol=TOL)
+    for q in (0, 7, 149):
+        s1, r1 = ivf.search(Q[q], k=k)
+        assert list(r1) == list(rows5[q])
+    ref_sc, ref_rows = R.topk_ip_exact(Q, X, k)
+    recall = np.mean([len(set(rows5[q]) & set(ref_rows[q])) / k for q in range(nq)])
+    assert recall > 0.3, recall
