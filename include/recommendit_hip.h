@@ -49,13 +49,15 @@ int rihip_device_arch(char* buf, int buf_len);
  * err_flag (device int, nullable) is set to 1 if an id is outside [0,n_rows) (row 0 is used).
  * workspace (nullable): rihip_tower_forward_workspace_floats(d, hidden, item) floats, 16-B aligned; holds the
  * MFMA-fragment-major copy of W1/W2 rebuilt each call (coalesced weight loads).
+ * seed_step_dev (nullable): device int64 mixed into the dropout seed, so a captured hipGraph draws a fresh
+ * mask on every replay (the counter is advanced by rihip_adam_hyper_step).
  * Supported (d,hidden): see rihip_tower_supported. */
 int rihip_tower_supported(int d, int hidden);
 int64_t rihip_tower_forward_workspace_floats(int d, int hidden, int item);
 int rihip_tower_forward(const float* table, int64_t n_rows, const int64_t* ids, const float* genres, int64_t B,
                         int d, int hidden, const float* W1, const float* b1, const float* W2, const float* b2,
                         int training, float dropout_p, uint64_t seed, int64_t row0, float* out, float* hid,
-                        float* denom, int* err_flag, float* workspace, void* stream);
+                        float* denom, int* err_flag, float* workspace, const int64_t* seed_step_dev, void* stream);
 
 /* Backward of the above (autograd of two_tower.py:39-42/:68-72, run by
  * src/training/train_embeddings.py:190).  grad_out = dL/d out [B,d].
@@ -113,7 +115,12 @@ int rihip_clip_coef(const double* part, int64_t n_part, float max_norm, float* c
 /* torch.optim.Adam(lr, betas, eps, weight_decay) single step with coupled L2
  * (train_embeddings.py:160,192); g is scaled by *clip_coef (nullable) first.  step >= 1. */
 int rihip_adam_dense(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                     float eps, float weight_decay, int64_t step, const float* clip_coef, void* stream);
+                     float eps, float weight_decay, int64_t step, const float* clip_coef, const float* hyper_dev,
+                     void* stream);
+/* Graph-replay clock: *step_dev += 1, then hyper_dev[0] = *lr_dev / (1 - beta1^t), hyper_dev[1] = sqrt(1 - beta2^t).
+ * Passing hyper_dev (non-NULL) to rihip_adam_dense / rihip_adam_rows overrides their host-side lr/step arguments. */
+int rihip_adam_hyper_step(int64_t* step_dev, const float* lr_dev, float beta1, float beta2, float* hyper_dev,
+                          void* stream);
 
 /* Row-sparse path for tables too large for a dense pass per step (SURVEY.md §7 hard part 1):
  * group (id,sample) pairs by id (radix sort), sum each row's contributions in sorted order
@@ -128,7 +135,7 @@ int rihip_rows_reduce(const float* dX, int64_t B, int d, const int64_t* uniq, vo
                       double* part, void* stream);
 int rihip_adam_rows(float* table, float* m, float* v, const int64_t* uniq, const float* Gc, int64_t B, int d,
                     void* workspace, float lr, float beta1, float beta2, float eps, float weight_decay,
-                    int64_t step, const float* clip_coef, void* stream);
+                    int64_t step, const float* clip_coef, const float* hyper_dev, void* stream);
 
 /* ---- inner-product index -------------------------------------------------------------------
  * Replaces faiss.IndexFlatIP / IndexIVFFlat(METRIC_INNER_PRODUCT) behind FAISSIndex

@@ -30,7 +30,7 @@ SIGNATURES = {
     "rihip_tower_supported": (C.c_int, [C.c_int, C.c_int]),
     "rihip_tower_forward_workspace_floats": (c_i64, [C.c_int, C.c_int, C.c_int]),
     "rihip_tower_forward": (C.c_int, [vp, c_i64, vp, vp, c_i64, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, C.c_float,
-                                      C.c_uint64, c_i64, vp, vp, vp, vp, vp, vp]),
+                                      C.c_uint64, c_i64, vp, vp, vp, vp, vp, vp, vp]),
     "rihip_tower_backward_workspace_floats": (c_i64, [c_i64, C.c_int, C.c_int, C.c_int]),
     "rihip_tower_backward": (C.c_int, [vp, c_i64, vp, vp, c_i64, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_float,
                                        vp, vp, vp, vp, vp, C.c_int, vp, vp]),
@@ -47,14 +47,15 @@ SIGNATURES = {
     "rihip_sumsq": (C.c_int, [vp, c_i64, vp, vp]),
     "rihip_clip_coef": (C.c_int, [vp, c_i64, C.c_float, vp, vp, vp]),
     "rihip_adam_dense": (C.c_int, [vp, vp, vp, vp, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, c_i64,
-                                   vp, vp]),
+                                   vp, vp, vp]),
+    "rihip_adam_hyper_step": (C.c_int, [vp, vp, C.c_float, C.c_float, vp, vp]),
     "rihip_rows_workspace_bytes": (c_i64, [c_i64, C.c_int]),
     "rihip_rows_nparts": (C.c_int, []),
     "rihip_rows_group": (C.c_int, [vp, c_i64, C.c_int, vp, vp, c_i64, vp]),
     "rihip_rows_n_unique_ptr": (C.c_int, [vp, c_i64, C.c_int, C.POINTER(vp)]),
     "rihip_rows_reduce": (C.c_int, [vp, c_i64, C.c_int, vp, vp, vp, vp, vp]),
     "rihip_adam_rows": (C.c_int, [vp, vp, vp, vp, vp, c_i64, C.c_int, vp, C.c_float, C.c_float, C.c_float, C.c_float,
-                                  C.c_float, c_i64, vp, vp]),
+                                  C.c_float, c_i64, vp, vp, vp]),
     "rihip_ip_index_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
     "rihip_ip_index_destroy": (C.c_int, [vp]),
     "rihip_ip_index_set_vectors": (C.c_int, [vp, vp, c_i64, C.c_int, vp]),

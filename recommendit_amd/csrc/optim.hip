@@ -63,9 +63,23 @@ __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v,
   p = p - h.lr_over_bc1 * (m / denom);
 }
 
+// device-resident step clock for graph replay: the bias-corrected step size of THIS step is computed on the device
+// from a step counter that the kernel itself advances (host constants baked into a captured graph would freeze t)
+__global__ void adam_hyper_kernel(int64_t* step, const float* lr, float b1, float b2, float* hyper) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const int64_t t = *step + 1;
+    *step = t;
+    const double bc1 = 1.0 - pow((double)b1, (double)t);
+    const double bc2 = 1.0 - pow((double)b2, (double)t);
+    hyper[0] = (float)((double)(*lr) / bc1);
+    hyper[1] = (float)sqrt(bc2);
+  }
+}
+
 __global__ __launch_bounds__(256) void adam_dense_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                          float* __restrict__ m, float* __restrict__ v, int64_t n,
-                                                         const float* coef_dev, AdamHyper h) {
+                                                         const float* coef_dev, AdamHyper h, const float* hyper_dev) {
+  if (hyper_dev) { h.lr_over_bc1 = hyper_dev[0]; h.sqrt_bc2 = hyper_dev[1]; }
   const float coef = coef_dev ? *coef_dev : 1.f;
   const int64_t stride = (int64_t)gridDim.x * 256;
   const int64_t n4 = n / 4;
@@ -180,7 +194,8 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ tabl
                                                         float* __restrict__ v, const int64_t* __restrict__ uniq,
                                                         const float* __restrict__ Gc,
                                                         const int* __restrict__ n_unique, int d,
-                                                        const float* coef_dev, AdamHyper h) {
+                                                        const float* coef_dev, AdamHyper h, const float* hyper_dev) {
+  if (hyper_dev) { h.lr_over_bc1 = hyper_dev[0]; h.sqrt_bc2 = hyper_dev[1]; }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nu = *n_unique;
   const float coef = coef_dev ? *coef_dev : 1.f;
@@ -230,8 +245,8 @@ extern "C" int rihip_clip_coef(const double* part, int64_t n_part, float max_nor
 
 extern "C" int rihip_adam_dense(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                                 float beta2, float eps, float weight_decay, int64_t step, const float* clip_coef,
-                                void* stream) {
-  RIHIP_REQUIRE(p && g && m && v && n >= 0 && step >= 1, RIHIP_ERR_ARG, "adam_dense: bad arguments");
+                                const float* hyper_dev, void* stream) {
+  RIHIP_REQUIRE(p && g && m && v && n >= 0 && (step >= 1 || hyper_dev), RIHIP_ERR_ARG, "adam_dense: bad arguments");
   RIHIP_REQUIRE(((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
                   reinterpret_cast<uintptr_t>(v)) & 15) == 0,
                 RIHIP_ERR_ARG, "adam_dense: pointers must be 16-byte aligned");
@@ -239,7 +254,15 @@ extern "C" int rihip_adam_dense(float* p, const float* g, float* m, float* v, in
   const int64_t nb = (n / 4 + 255) / 256;
   const int grid = (int)(nb < 1 ? 1 : (nb < 2048 ? nb : 2048));
   hipLaunchKernelGGL(adam_dense_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, clip_coef,
-                     make_hyper(lr, beta1, beta2, eps, weight_decay, step));
+                     make_hyper(lr, beta1, beta2, eps, weight_decay, step >= 1 ? step : 1), hyper_dev);
+  RIHIP_CHECK_LAUNCH();
+  return RIHIP_OK;
+}
+
+extern "C" int rihip_adam_hyper_step(int64_t* step_dev, const float* lr_dev, float beta1, float beta2, float* hyper_dev,
+                                     void* stream) {
+  RIHIP_REQUIRE(step_dev && lr_dev && hyper_dev, RIHIP_ERR_ARG, "adam_hyper_step: null pointer");
+  hipLaunchKernelGGL(adam_hyper_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_dev, lr_dev, beta1, beta2, hyper_dev);
   RIHIP_CHECK_LAUNCH();
   return RIHIP_OK;
 }
@@ -336,13 +359,15 @@ extern "C" int rihip_rows_reduce(const float* dX, int64_t B, int d, const int64_
 
 extern "C" int rihip_adam_rows(float* table, float* m, float* v, const int64_t* uniq, const float* Gc, int64_t B,
                                int d, void* workspace, float lr, float beta1, float beta2, float eps,
-                               float weight_decay, int64_t step, const float* clip_coef, void* stream) {
-  RIHIP_REQUIRE(table && m && v && uniq && Gc && workspace && B > 0 && step >= 1, RIHIP_ERR_ARG,
+                               float weight_decay, int64_t step, const float* clip_coef, const float* hyper_dev,
+                               void* stream) {
+  RIHIP_REQUIRE(table && m && v && uniq && Gc && workspace && B > 0 && (step >= 1 || hyper_dev), RIHIP_ERR_ARG,
                 "adam_rows: bad arguments");
   RowsWs ws;
   RIHIP_REQUIRE(rows_ws_layout(B, d, workspace, &ws) == RIHIP_OK, RIHIP_ERR_HIP, "adam_rows: size query failed");
   hipLaunchKernelGGL(adam_rows_kernel, dim3(ROWS_GRID), dim3(256), 0, (hipStream_t)stream, table, m, v, uniq, Gc,
-                     ws.n_unique, d, clip_coef, make_hyper(lr, beta1, beta2, eps, weight_decay, step));
+                     ws.n_unique, d, clip_coef, make_hyper(lr, beta1, beta2, eps, weight_decay, step >= 1 ? step : 1),
+                     hyper_dev);
   RIHIP_CHECK_LAUNCH();
   return RIHIP_OK;
 }

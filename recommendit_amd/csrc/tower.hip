@@ -105,6 +105,7 @@ struct TowerFwdArgs {
   uint32_t thresh24;
   float scale;      // 1/(1-p)
   int64_t row0;     // global row offset for the dropout counter
+  const int64_t* seed_step;  // optional device step counter mixed into the dropout seed (graph replay)
   int* err_flag;    // set to 1 on out-of-range id (nullable)
 };
 
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(256, 2) void tower_fwd_kernel(TowerFwdArgs a) {
   }
   const float b1v = a.b1[ct1 * 32 + (lane & 31)];
   const float b2v = a.b2[ct2 * 32 + (lane & 31)];
+  const uint64_t seed_mul = a.seed_step ? rihip_splitmix64(a.seed_mul + (uint64_t)(*a.seed_step)) : a.seed_mul;
 
   const int64_t ntiles = (a.B + TM - 1) / TM;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void tower_fwd_kernel(TowerFwdArgs a) {
           const int64_t grow = row_base + row;
           float v = fmaxf(acc[t][r] + b1v, 0.f);
           if (a.training) {
-            const bool keep = rihip_keep(a.seed_mul, (uint64_t)(a.row0 + grow) * H + col, a.thresh24);
+            const bool keep = rihip_keep(seed_mul, (uint64_t)(a.row0 + grow) * H + col, a.thresh24);
             v = keep ? v * a.scale : 0.f;
           }
           Hs[row * LDH + col] = v;
@@ -529,7 +531,7 @@ extern "C" int rihip_tower_forward(const float* table, int64_t n_rows, const int
                                    int64_t B, int d, int hidden, const float* W1, const float* b1, const float* W2,
                                    const float* b2, int training, float dropout_p, uint64_t seed, int64_t row0,
                                    float* out, float* hid, float* denom, int* err_flag, float* workspace,
-                                   void* stream) {
+                                   const int64_t* seed_step_dev, void* stream) {
   RIHIP_REQUIRE(rihip_tower_supported(d, hidden), RIHIP_ERR_SHAPE,
                 "tower_forward: unsupported (embed_dim=%d, hidden_dim=%d)", d, hidden);
   RIHIP_REQUIRE(B >= 0 && n_rows > 0, RIHIP_ERR_ARG, "tower_forward: bad sizes B=%lld n_rows=%lld", (long long)B,
@@ -545,7 +547,7 @@ extern "C" int rihip_tower_forward(const float* table, int64_t n_rows, const int
   a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.out = out; a.hid = hid; a.denom = denom;
   a.training = (training && dropout_p > 0.f) ? 1 : 0;
   a.seed_mul = rihip_seed_mul(seed); a.thresh24 = rihip_thresh24(dropout_p);
-  a.scale = 1.f / (1.f - dropout_p); a.row0 = row0; a.err_flag = err_flag;
+  a.scale = 1.f / (1.f - dropout_p); a.row0 = row0; a.err_flag = err_flag; a.seed_step = seed_step_dev;
   const int64_t ntiles = (B + TM - 1) / TM;
   const int wgs_per_cu = 2;  // the forward kernel is built for 2 workgroups per CU (launch bounds)
   const int grid = (int)(ntiles < wgs_per_cu * RIHIP_NCU ? ntiles : wgs_per_cu * RIHIP_NCU);

@@ -64,10 +64,10 @@ class _RowsOpt:
                                       self.Gc.data_ptr(), part_ptr, st), "rows_reduce")
         self._B = B
 
-    def adam(self, lr, b1, b2, eps, wd, step, coef_ptr, st) -> None:
+    def adam(self, lr, b1, b2, eps, wd, step, coef_ptr, st, hyper_ptr=None) -> None:
         L.check(L.lib().rihip_adam_rows(self.table.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                         self.uniq.data_ptr(), self.Gc.data_ptr(), self._B, self.d, self.ws.data_ptr(),
-                                        lr, b1, b2, eps, wd, step, coef_ptr, st), "adam_rows")
+                                        lr, b1, b2, eps, wd, step, coef_ptr, hyper_ptr, st), "adam_rows")
 
 
 class _DenseOpt:
@@ -87,17 +87,17 @@ class _DenseOpt:
     def sumsq(self, part_ptr: int, st: int) -> None:
         L.check(L.lib().rihip_sumsq(self.grad.data_ptr(), self.grad.numel(), part_ptr, st), "sumsq")
 
-    def adam(self, lr, b1, b2, eps, wd, step, coef_ptr, st) -> None:
+    def adam(self, lr, b1, b2, eps, wd, step, coef_ptr, st, hyper_ptr=None) -> None:
         L.check(L.lib().rihip_adam_dense(self.table.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(),
                                          self.v.data_ptr(), self.table.numel(), lr, b1, b2, eps, wd, step, coef_ptr,
-                                         st), "adam_dense")
+                                         hyper_ptr, st), "adam_dense")
 
 
 class HipBPRTrainer:
     def __init__(self, model: TwoTowerModel, batch_size: int, lr: float = 1e-3, weight_decay: float = 1e-5,
                  betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = 1.0, loss_mode: str = "sampled",
                  table_opt: str = "dense", seed: int = 0, process_group=None, user_row_offset: int = 0,
-                 inbatch_precision: int = 0):
+                 inbatch_precision: int = 0, use_graph: bool = False):
         assert loss_mode in ("sampled", "inbatch") and table_opt in ("dense", "sparse")
         self.lib = L.lib()
         self.model = model
@@ -108,7 +108,10 @@ class HipBPRTrainer:
         self.step_count = 0
         self.seed = seed
         self.inbatch_precision = int(inbatch_precision)  # 0 = exact f32 MFMA, 1 = split-bf16 (bf16x3)
-        self.sweep_events = None  # bench hook: list collecting (start, end) events around every sweep launch
+        self.sweep_events = None
+        self.use_graph = bool(use_graph)
+        self._graph = None
+        self._eager_steps = 0  # bench hook: list collecting (start, end) events around every sweep launch
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
         self.rank = dist.get_rank(process_group) if self.world > 1 else 0
@@ -157,6 +160,11 @@ class HipBPRTrainer:
         self.dU = torch.empty((B, d), **f32); self.dI = torch.empty((nI, d), **f32)
         self.dXu = torch.empty((B, d), **f32); self.dXi = torch.empty((nI, d), **f32)
         self.loss = torch.zeros((), **f32)
+        # device-resident step clock (graph replay must not bake host constants): step counter, lr, {lr/bc1, sqrt(bc2)}
+        self.step_dev = torch.zeros((1,), dtype=torch.int64, device=self.dev)
+        self.lr_dev = torch.full((1,), float(lr), **f32)
+        self.hyper_dev = torch.zeros((2,), **f32)
+        self._lr_host = float(lr)
         self.coef = torch.ones((1,), **f32); self.gnorm = torch.zeros((1,), **f32)
         self.err = torch.zeros((1,), dtype=torch.int32, device=self.dev)
         nws = max(self.lib.rihip_tower_backward_workspace_floats(B, d, H, 0),
@@ -191,8 +199,8 @@ class HipBPRTrainer:
                                              self.pv[keys[1]].data_ptr(), self.pv[keys[2]].data_ptr(),
                                              self.pv[keys[3]].data_ptr(), 1 if training else 0, self.p_drop, seed, 0,
                                              out.data_ptr(), hid.data_ptr(), den.data_ptr(), self.err.data_ptr(),
-                                             (self.fws_u if genres is None else self.fws_i).data_ptr(), self._st),
-                "tower_forward")
+                                             (self.fws_u if genres is None else self.fws_i).data_ptr(),
+                                             self.step_dev.data_ptr(), self._st), "tower_forward")
 
     def _bwd(self, table, ids, genres, keys, gout, out, den, hid, dX):
         scale = 1.0 / (1.0 - self.p_drop) if (self.model.training and self.p_drop > 0) else 1.0
@@ -208,15 +216,41 @@ class HipBPRTrainer:
              lr: Optional[float] = None) -> torch.Tensor:
         """One optimisation step.  user_ids int64 [B] (LOCAL row ids when tables are sharded);
         sampled mode: item_ids [2B] = pos || neg, item_genres [2B,18]; inbatch: [B] / [B,18].
-        Returns the loss as a 0-dim device tensor (no host sync)."""
-        lib, B, d = self.lib, self.B, self.d
-        assert user_ids.numel() == B and item_ids.numel() == self.I.shape[0]
-        self._st = st = L.stream_ptr()
+        Returns the loss as a 0-dim device tensor (no host sync).
+
+        use_graph=True (single GPU): the second call captures the whole step (~45 launches) into a hipGraph;
+        later calls copy the ids into static buffers and replay it.  The Adam step clock and the dropout seed
+        offset live in device memory (rihip_adam_hyper_step), so replays advance them."""
+        assert user_ids.numel() == self.B and item_ids.numel() == self.I.shape[0]
+        lr = self.lr if lr is None else float(lr)
+        if lr != self._lr_host:
+            self.lr_dev.fill_(lr)
+            self._lr_host = lr
         self.step_count += 1
-        t = self.step_count
-        lr = self.lr if lr is None else lr
+        if not (self.use_graph and self.world == 1 and self.sweep_events is None):
+            return self._step_impl(user_ids, item_ids, item_genres)
+        if self._graph is None:
+            if self._eager_steps < 1:      # first call eager: warms the library (rocPRIM temp queries, lazy module load)
+                self._eager_steps += 1
+                return self._step_impl(user_ids, item_ids, item_genres)
+            self._s_u = user_ids.clone(); self._s_i = item_ids.clone(); self._s_g = item_genres.clone()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._step_impl(self._s_u, self._s_i, self._s_g)
+            self._graph = g
+        self._s_u.copy_(user_ids); self._s_i.copy_(item_ids); self._s_g.copy_(item_genres)
+        self._graph.replay()
+        return self.loss
+
+    def _step_impl(self, user_ids: torch.Tensor, item_ids: torch.Tensor, item_genres: torch.Tensor) -> torch.Tensor:
+        lib, B, d = self.lib, self.B, self.d
+        self._st = st = L.stream_ptr()
+        L.check(lib.rihip_adam_hyper_step(self.step_dev.data_ptr(), self.lr_dev.data_ptr(), self.b1, self.b2,
+                                          self.hyper_dev.data_ptr(), st), "adam_hyper_step")
+        t, lr = 0, 0.0   # the device clock (hyper_dev) overrides the host-side step / lr arguments below
         ukeys, ikeys = _MLP_KEYS[:4], _MLP_KEYS[4:]
-        s0 = (self.seed * 1000003 + t * 2 + self.rank * 7919) & ((1 << 62) - 1)
+        s0 = (self.seed * 1000003 + self.rank * 7919) & ((1 << 62) - 1)   # + device step counter inside the kernel
         self._fwd(self.utab, user_ids, None, ukeys, self.U, self.hidU, self.denU, s0)
         self._fwd(self.itab, item_ids, item_genres, ikeys, self.I, self.hidI, self.denI, s0 + 1)
 
@@ -264,9 +298,10 @@ class HipBPRTrainer:
         cp = self.coef.data_ptr()
         L.check(lib.rihip_adam_dense(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
                                      self.flat_v.data_ptr(), self.flat_p.numel(), lr, self.b1, self.b2, self.eps,
-                                     self.wd, t, cp, st), "adam_dense")
-        self.uopt.adam(lr, self.b1, self.b2, self.eps, self.wd, t, cp, st)
-        self.iopt.adam(lr, self.b1, self.b2, self.eps, self.wd, t, cp, st)
+                                     self.wd, t, cp, self.hyper_dev.data_ptr(), st), "adam_dense")
+        hp = self.hyper_dev.data_ptr()
+        self.uopt.adam(lr, self.b1, self.b2, self.eps, self.wd, t, cp, st, hp)
+        self.iopt.adam(lr, self.b1, self.b2, self.eps, self.wd, t, cp, st, hp)
         return self.loss
 
     def _sweep(self, *args) -> None:

@@ -74,7 +74,7 @@ class _TowerFn(torch.autograd.Function):
         L.check(lib.rihip_tower_forward(table_c.data_ptr(), table_c.shape[0], ids_d.data_ptr(), L.ptr(g_d), B, d, H,
                                         W1c.data_ptr(), b1c.data_ptr(), W2c.data_ptr(), b2c.data_ptr(),
                                         1 if training else 0, float(p), seed, 0, out.data_ptr(), hid.data_ptr(),
-                                        denom.data_ptr(), err.data_ptr(), ws.data_ptr(), L.stream_ptr()),
+                                        denom.data_ptr(), err.data_ptr(), ws.data_ptr(), None, L.stream_ptr()),
                 "tower_forward")
         ctx.save_for_backward(table_c, W1c, W2c, ids_d, g_d, out, hid, denom)
         ctx.scale = 1.0 / (1.0 - p) if (training and p > 0) else 1.0

@@ -27,13 +27,16 @@ def _params(sd, tower):
                          sd[f"{tower}.mlp.3.weight"], sd[f"{tower}.mlp.3.bias"])
 
 
-def test_g4_train50_golden_fused_dense(golden_dir):
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_g4_train50_golden_fused_dense(golden_dir, use_graph):
+    """use_graph=True: the step is captured into a hipGraph on the second call and replayed 48 times; the device-side
+    Adam clock and the lr scalar must keep the run on the reference's trajectory (incl. the mid-run lr change)."""
     from recommendit_amd.trainer import HipBPRTrainer, cosine_lr
     g = np.load(golden_dir / "g4_train50.npz")
     nu, ni, d, H, seed, B = (int(x) for x in g["cfg"])
     m, sd = _model(nu, ni, d, H, seed)
     m.train()
-    tr = HipBPRTrainer(m, B, lr=1e-2, weight_decay=1e-5, loss_mode="sampled", table_opt="dense")
+    tr = HipBPRTrainer(m, B, lr=1e-2, weight_decay=1e-5, loss_mode="sampled", table_opt="dense", use_graph=use_graph)
     epoch = 0
     for step in range(50):
         u, p, gp, n, gn = fx.make_batch(nu, ni, B, seed=4000 + step, boundary=False)
@@ -41,8 +44,28 @@ def test_g4_train50_golden_fused_dense(golden_dir):
         assert abs(loss.item() - g["losses"][step]) < 5e-5, step
         if step == 24:
             epoch += 1
+    assert (tr._graph is not None) == use_graph
     for k, prm in m.named_parameters():   # module parameters are views of the trainer's buffers
         np.testing.assert_allclose(prm.detach().cpu().numpy(), g[f"final_{k}"], atol=2e-4, rtol=0, err_msg=k)
+
+
+def test_graph_replay_equals_eager_sparse_inbatch():
+    """row-sparse optimiser (rocPRIM sort/scan inside the captured region) + in-batch sweep: graph == eager, bitwise."""
+    from recommendit_amd.trainer import HipBPRTrainer
+    nu, ni, d, H, B = 300, 150, 64, 128, 96
+    outs = []
+    for use_graph in (False, True):
+        m, sd = _model(nu, ni, d, H, seed=3, dropout=0.2)
+        m.train()
+        tr = HipBPRTrainer(m, B, lr=5e-3, loss_mode="inbatch", table_opt="sparse", seed=7, use_graph=use_graph)
+        losses = []
+        for step in range(6):
+            u, p, gp, n, gn = fx.make_batch(nu, ni, B, seed=step * 13, boundary=False)
+            losses.append(tr.step(t(u), t(p), t(gp)).item())
+        outs.append((losses, {k: v.detach().clone() for k, v in m.named_parameters()}))
+    assert outs[0][0] == outs[1][0]
+    for k in outs[0][1]:
+        assert torch.equal(outs[0][1][k], outs[1][1][k]), k
 
 
 def _oracle_step(sd, mom, u, p, gp, n, gn, step, lr, mode, sparse):

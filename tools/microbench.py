@@ -57,5 +57,30 @@ def main():
     print(f"full sampled step: {t:8.1f} us  -> {B / t:6.2f} M pairs/s")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 2 and sys.argv[2] == "small"):
     main()
+
+
+def small_batch(B=1024, d=64, H=128, n=200):
+    """launch-bound regime (the reference's default batch): eager vs hipGraph replay"""
+    import time
+    dev = torch.device("cuda")
+    for use_graph in (False, True):
+        m = TwoTowerModel(6040, 3952, d, H, dropout=0.1)
+        m.train()
+        tr = HipBPRTrainer(m, B, loss_mode="sampled", table_opt="dense", use_graph=use_graph)
+        g = torch.Generator(device=dev); g.manual_seed(0)
+        u = torch.randint(1, 6040, (B,), device=dev, generator=g)
+        it = torch.randint(1, 3952, (2 * B,), device=dev, generator=g)
+        gen = (torch.rand((2 * B, 18), device=dev, generator=g) < 0.1).float()
+        for _ in range(5):
+            tr.step(u, it, gen)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n):
+            tr.step(u, it, gen)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+        print(f"B={B} d={d} dense-Adam sampled step, use_graph={use_graph}: {dt * 1e6:8.1f} us/step -> {B / dt / 1e6:6.2f} M pairs/s")
+
+
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "small":
+    small_batch(256); small_batch(1024); small_batch(8192)
