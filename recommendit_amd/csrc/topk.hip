@@ -66,6 +66,7 @@ struct ScanArgs {
   const int* blk_ntiles;      // [query blocks]
   int64_t n_scan_tiles;
   int tile_step;              // IVF threshold sample: visit every tile_step-th tile of the block list (0/1 = all)
+  int qgrid;                  // bf16 filter: number of query blocks (1-D XCD-aware launch)
 };
 
 constexpr int TRS = 32;  // corpus rows per LDS tile of the scan kernel
@@ -260,7 +261,13 @@ __global__ __launch_bounds__(256) void rownorm_max_kernel(const float* __restric
 constexpr int QBB = 256;  // queries per workgroup of the bf16 filter (64 per wave: two 32-query groups)
 
 constexpr int TRB = 64;     // corpus rows per pipeline stage of the bf16 filter (two 32-row MFMA sub-tiles)
-constexpr int QCOLS = 256;  // survivor queue: 16-score accumulator columns per workgroup (LDS)
+constexpr int QCOLS = 192;  // survivor queue: 16-score accumulator columns per workgroup (LDS)
+
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {  // no NaN-canonicalising pre-ops
+  float m;
+  asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(a), "v"(b), "v"(c));
+  return m;
+}
 
 // queue full (dense survivors): append this column's survivors straight to the query's candidate list.  Kept out of
 // line so that its global atomics/stores do not make hipcc drain the prefetch in the hot loop.
@@ -280,10 +287,10 @@ __device__ __noinline__ void scan_slow_append(const float* col16, float th, int6
 // so the hot loop contains no global store/atomic (those make hipcc drain the in-flight prefetch with vmcnt(0)).
 // DENSE=true: every score is stored at slot = virtual row (threshold-sample pass).
 template <int D, bool DENSE>
-__global__ __launch_bounds__(256, 2) void scan_bf16_kernel(ScanArgs a) {
+__global__ __launch_bounds__(256, 3) void scan_bf16_kernel(ScanArgs a) {
   constexpr int LDB = D + 8, KB = D / 16;
   constexpr int NV = (TRB * (D / 8) + 255) / 256;  // 16-byte pieces staged per thread per stage
-  __shared__ __attribute__((aligned(16))) __bf16 Xs[3][TRB * LDB];
+  __shared__ __attribute__((aligned(16))) __bf16 Xs[2][TRB * LDB];
   // A survivor is rare per lane but not per 64-lane wave, so the hot path must stay tiny: a lane whose 16-score
   // column holds a candidate just dumps the whole column (4 x ds_write_b128 + header) into this queue; thresholding
   // per element and the global appends happen in flush(), amortised over ~128 columns.
@@ -293,7 +300,14 @@ __global__ __launch_bounds__(256, 2) void scan_bf16_kernel(ScanArgs a) {
   const __bf16* Xb = reinterpret_cast<const __bf16*>(a.Xb);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r31 = lane & 31, hh = lane >> 5;
-  const int64_t qb0 = (int64_t)blockIdx.x * QBB;
+  // XCD-aware block map (workgroups are dealt round-robin over the 8 XCDs, each with its own L2): all query blocks
+  // that stream the SAME corpus split are placed on one XCD and next to each other in dispatch order, so a corpus
+  // tile is fetched from HBM once per XCD instead of once per query block.  Pure speed: any placement is correct.
+  const unsigned lin = blockIdx.x;
+  const unsigned xcd = lin & 7u, kk = lin >> 3;
+  const unsigned bx = kk % (unsigned)a.qgrid, by = (kk / (unsigned)a.qgrid) * 8u + xcd;
+  if ((int)by >= a.nsplit) return;
+  const int64_t qb0 = (int64_t)bx * QBB;
   const int ql0 = w * 64 + r31, ql1 = ql0 + 32;  // block-local query index of this lane's two query groups
   const bool ok0 = qb0 + ql0 < a.nq, ok1 = qb0 + ql1 < a.nq;
   const int64_t qr0 = ok0 ? qb0 + ql0 : a.nq - 1, qr1 = ok1 ? qb0 + ql1 : a.nq - 1;
@@ -313,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void scan_bf16_kernel(ScanArgs a) {
   }
   const int64_t n_seq = (a.n_virtual + TRB - 1) / TRB;
   const int64_t per = (n_seq + a.nsplit - 1) / a.nsplit;
-  const int64_t i0 = (int64_t)blockIdx.y * per;
+  const int64_t i0 = (int64_t)by * per;
   const int64_t i1 = (i0 + per < n_seq) ? i0 + per : n_seq;
   if (i0 >= i1) return;
   if (tid == 0) q_cnt = 0;
@@ -353,9 +367,14 @@ __global__ __launch_bounds__(256, 2) void scan_bf16_kernel(ScanArgs a) {
       }
       return;
     }
-    float mx = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
-#pragma unroll
-    for (int r = 4; r < 16; r += 4) mx = fmaxf(mx, fmaxf(fmaxf(acc[r], acc[r + 1]), fmaxf(acc[r + 2], acc[r + 3])));
+    float mx = max3_raw(acc[0], acc[1], acc[2]);
+    mx = max3_raw(mx, acc[3], acc[4]);
+    mx = max3_raw(mx, acc[5], acc[6]);
+    mx = max3_raw(mx, acc[7], acc[8]);
+    mx = max3_raw(mx, acc[9], acc[10]);
+    mx = max3_raw(mx, acc[11], acc[12]);
+    mx = max3_raw(mx, acc[13], acc[14]);
+    mx = fmaxf(mx, acc[15]);
     if (!(mx >= th)) return;  // no survivor in this 16-score column (the common case)
     const unsigned pos = atomicAdd(&q_cnt, 1u);  // LDS
     if (pos < (unsigned)QCOLS) {
@@ -409,17 +428,13 @@ __global__ __launch_bounds__(256, 2) void scan_bf16_kernel(ScanArgs a) {
 
   load_tile(i0);
   store_tile(0);
-  if (i0 + 1 < i1) {
-    load_tile(i0 + 1);
-    store_tile(1);
-  }
   __syncthreads();
 #pragma unroll 1
   for (int64_t i = i0; i < i1; ++i) {
-    const int it = (int)((i - i0) % 3);
-    if (i + 2 < i1) load_tile(i + 2);
+    const int it = (int)((i - i0) & 1);
+    if (i + 1 < i1) load_tile(i + 1);   // in flight during this stage's MFMA work (3 workgroups per CU interleave)
     compute(it, i);
-    if (i + 2 < i1) store_tile((it + 2) % 3);
+    if (i + 1 < i1) store_tile(it ^ 1);
     __syncthreads();
     if (!DENSE && q_cnt >= (unsigned)(QCOLS / 2)) flush();  // uniform: q_cnt is read after the barrier
   }
@@ -947,12 +962,13 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
     if (two_prec) {
       x.Xb = h->Xb;
       const int64_t qblocks = qgrid_b;
-      int64_t ns = (2 * RIHIP_NCU + qblocks - 1) / qblocks;
+      int64_t ns = (3 * RIHIP_NCU + qblocks - 1) / qblocks;  // 3 resident workgroups per CU (launch bounds)
       if (ns > tiles) ns = tiles;
       if (ns < 1) ns = 1;
       if (ns > 65535) ns = 65535;
       x.nsplit = (int)ns;
-      const dim3 grid(qgrid_b, (unsigned)x.nsplit);
+      x.qgrid = (int)qgrid_b;
+      const dim3 grid(qgrid_b * 8u * (unsigned)((x.nsplit + 7) / 8));
       if (x.dense) {
         if (d == 32) hipLaunchKernelGGL((scan_bf16_kernel<32, true>), grid, dim3(256), 0, st, x);
         else if (d == 64) hipLaunchKernelGGL((scan_bf16_kernel<64, true>), grid, dim3(256), 0, st, x);
