@@ -84,7 +84,7 @@ def test_status_codes_not_aborts():
     assert l.rihip_gbdt_load_text(b"/nonexistent/model.txt", ctypes.byref(h)) != 0 and b"cannot open" in l.rihip_last_error()
     x = torch.zeros(8, device="cuda")
     assert l.rihip_adam_dense(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), 8, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0,
-                              None, None) != 0        # step must be >= 1
+                              None, None, None) != 0  # step must be >= 1 when no device clock is given
     with pytest.raises(RuntimeError, match="no HIP kernel instantiation|unsupported"):
         from recommendit_amd import TwoTowerModel
         TwoTowerModel(5, 5, embed_dim=48, hidden_dim=64).user_tower(torch.tensor([1]))
