@@ -734,11 +734,6 @@ __global__ __launch_bounds__(256) void ivf_probe_kernel(const float* __restrict_
   }
 }
 
-__global__ void zero_int_kernel(int* p, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = 0;
-}
-
 // ------------------------------------------ handle ---------------------------------------------
 __global__ void fill_int_kernel(int* p, int64_t n, int v) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

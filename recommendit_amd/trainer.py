@@ -29,7 +29,7 @@ import torch.distributed as dist
 
 from . import _lib as L
 from .dist_utils import all_gather_into, all_reduce_sum_
-from .two_tower import N_GENRES, TwoTowerModel
+from .two_tower import TwoTowerModel
 
 _MLP_KEYS = ["user_tower.mlp.0.weight", "user_tower.mlp.0.bias", "user_tower.mlp.3.weight", "user_tower.mlp.3.bias",
              "item_tower.mlp.0.weight", "item_tower.mlp.0.bias", "item_tower.mlp.3.weight", "item_tower.mlp.3.bias"]

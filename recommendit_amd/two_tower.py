@@ -14,7 +14,6 @@ every forward raises RuntimeError.
 from __future__ import annotations
 
 import logging
-import math
 import os
 from pathlib import Path
 from typing import Dict, List, Optional, Tuple
@@ -35,10 +34,6 @@ _CHECK_IDS = os.environ.get("RECOMMENDIT_CHECK_IDS", "0") == "1"  # device-side 
 def _next_seed() -> int:
     """Per-call dropout seed drawn from torch's global generator (so torch.manual_seed governs it)."""
     return int(torch.randint(0, 2**62, (1,), dtype=torch.int64).item())
-
-
-def _param_device() -> torch.device:
-    return L.device() if L.have_gpu() else torch.device("cpu")
 
 
 class _TowerFn(torch.autograd.Function):
