@@ -238,6 +238,23 @@ def main():
                                     "frac_of_f32_mfma_roofline": sp * 617472 / (PEAK_F32_MFMA_TFLOPS * 1e12 * world),
                                     "frac_of_hbm_roofline": sp * 9384 / (8.0e12 * world)}
         log(f"[bench] sampled: {sp:,.0f} pairs/s, {dts / K * 1e3:.2f} ms/step")
+        # -------------------------------------------------------------- BASELINE.json configs[0]/[1] shapes (1 GPU only)
+        if world == 1:
+            for tag, (bb, mode) in {"cfg1_ml1m_d64_b256_sampled": (256, "sampled"),
+                                    "cfg2_ml1m_d64_b8192_inbatch": (8192, "inbatch")}.items():
+                m2 = make_model(6040, 3952, 64, 128, seed=5)
+                # dense Adam + L2 on every row = the reference's exact optimiser semantics (tables are 2.5 MB)
+                t2 = HipBPRTrainer(m2, bb, loss_mode=mode, table_opt="dense", seed=1)
+                b2 = make_batches(8, bb, 6040, 3952, dev, seed=11, sampled=(mode == "sampled"))
+                for i in range(5):
+                    t2.step(*b2[i % 8])
+                n2 = 50
+                d2 = timed(lambda i: t2.step(*b2[i % 8]), n2, 1)
+                secondary[tag] = {"metric": "bpr_pairs_per_sec", "value": bb * n2 / d2, "unit": "pairs/s",
+                                  "ms_per_step": d2 / n2 * 1e3, "batch": bb, "loss_mode": mode,
+                                  "tables": "6041x64 + 3953x64 (MovieLens-1M shape), dense Adam+L2 (exact reference optimiser)"}
+                log(f"[bench] {tag}: {bb * n2 / d2:,.0f} pairs/s, {d2 / n2 * 1e3:.3f} ms/step")
+                del t2, m2, b2
         # -------------------------------------------------------------- top-500 brute-force IP retrieval
         from recommendit_amd import FAISSIndex
         g = torch.Generator(device=dev); g.manual_seed(1)
