@@ -13,8 +13,23 @@ def _staged(t: torch.Tensor, group) -> bool:
     return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
-def all_gather_into(out: torch.Tensor, inp: torch.Tensor, group=None) -> None:
-    """out[rank*n:(rank+1)*n] = inp of that rank (row-major concatenation over ranks)."""
+class _Done:
+    def wait(self) -> None:
+        return None
+
+
+def all_gather_into(out: torch.Tensor, inp: torch.Tensor, group=None, async_op: bool = False):
+    """out[rank*n:(rank+1)*n] = inp of that rank (row-major concatenation over ranks).
+    async_op=True (RCCL only): returns a work handle; the collective runs on RCCL's stream, ordered after the kernels
+    already queued on the current stream, and `handle.wait()` orders later kernels after it -- lets an all-gather
+    that is only needed two kernels later overlap with the kernel in between."""
+    if inp.is_cuda and not _staged(inp, group) and async_op:
+        return dist.all_gather_into_tensor(out, inp.contiguous(), group=group, async_op=True)
+    _all_gather_sync(out, inp, group)
+    return _Done()
+
+
+def _all_gather_sync(out: torch.Tensor, inp: torch.Tensor, group=None) -> None:
     if _staged(inp, group):
         W = dist.get_world_size(group)
         parts = [torch.empty(inp.shape, dtype=inp.dtype) for _ in range(W)]

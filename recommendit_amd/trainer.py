@@ -265,15 +265,18 @@ class HipBPRTrainer:
         else:
             self._inbatch(st)
 
-        self._bwd(self.utab, user_ids, None, ukeys, self.dU, self.U, self.denU, self.hidU, self.dXu)
+        # item tower first: its row gradients travel (all-gather) while the user tower's backward runs
         self._bwd(self.itab, item_ids, item_genres, ikeys, self.dI, self.I, self.denI, self.hidI, self.dXi)
-
-        # ---- gradient exchange (multi-GPU) + global grad norm -> clip coef (device scalar)
         iid, dXi = item_ids, self.dXi
         if self.world > 1:
+            w_i = all_gather_into(self.iid_all, item_ids, self.pg, async_op=True)
+            w_x = all_gather_into(self.dXi_all, self.dXi, self.pg, async_op=True)
+        self._bwd(self.utab, user_ids, None, ukeys, self.dU, self.U, self.denU, self.hidU, self.dXu)
+
+        # ---- gradient exchange (multi-GPU) + global grad norm -> clip coef (device scalar)
+        if self.world > 1:
             all_reduce_sum_(self.flat_g, self.pg)
-            all_gather_into(self.iid_all, item_ids, self.pg)
-            all_gather_into(self.dXi_all, self.dXi, self.pg)
+            w_i.wait(); w_x.wait()
             iid, dXi = self.iid_all, self.dXi_all
         pp = self.part.data_ptr()
         L.check(lib.rihip_sumsq(self.flat_g.data_ptr(), self.flat_g.numel(), pp, st), "sumsq")
@@ -332,12 +335,14 @@ class HipBPRTrainer:
         G, off = W * B, self.rank * B
         L.check(lib.rihip_rowdot(self.U.data_ptr(), self.I.data_ptr(), B, 0, d, self.pos.data_ptr(), st), "rowdot")
         all_gather_into(self.I_all, self.I, self.pg)
-        all_gather_into(self.U_all, self.U, self.pg)
-        all_gather_into(self.pos_all, self.pos, self.pg)
+        # U_all / pos_all are only read by the item-mode sweep: they travel under the user-mode sweep
+        w_u = all_gather_into(self.U_all, self.U, self.pg, async_op=True)
+        w_p = all_gather_into(self.pos_all, self.pos, self.pg, async_op=True)
         self._sweep(1, self.U.data_ptr(), B, off, self.I_all.data_ptr(), G, 0, d,
                                         self.pos.data_ptr(), None, G, self.dU.data_ptr(), self.r.data_ptr(),
                                         self.lpart.data_ptr(), self.sws.data_ptr(), self.inbatch_precision, st)
         all_gather_into(self.r_all, self.r, self.pg)
+        w_u.wait(); w_p.wait()
         self._sweep(0, self.I.data_ptr(), B, off, self.U_all.data_ptr(), G, 0, d,
                                         self.pos_all.data_ptr(), self.r_all.data_ptr(), G, self.dI.data_ptr(), None,
                                         None, self.sws.data_ptr(), self.inbatch_precision, st)
