@@ -182,24 +182,49 @@ def main():
     tr.sweep_events = None
     loss = float(tr.loss.item())
     pairs_per_s = G * K / dt
-    sweep_ms = [a.elapsed_time(b) for a, b in ev]
-    n_launch = len(sweep_ms)                          # one bracket per launch (user-mode and item-mode sweeps)
-    t_launch = sum(sweep_ms) / 1e3 / max(n_launch, 1)
-    flop_launch = 3.0 * B * G * D                     # algorithmic: 6*B_neg*d per pair / 2 launches
-    achieved = flop_launch / t_launch / 1e12 if t_launch > 0 else 0.0
-    traffic = None
+    by = {}
+    for what, e0, e1 in ev:                            # one bracket per launch, keyed by the C-ABI call
+        by.setdefault(what, []).append(e0.elapsed_time(e1))
+    mean_ms = {k: sum(v) / len(v) for k, v in by.items()}
+    traffic_tab = {}
     tf = ROOT / "profiles" / "traffic.json"
     if tf.exists():
         try:
-            traffic = json.loads(tf.read_text()).get(f"inbatch_sweep_n{world}")
+            traffic_tab = json.loads(tf.read_text())
         except Exception:
-            traffic = None
-    roofline = {"bound": "mfma", "kernel": "inbatch_sweep_kernel<128>", "achieved": achieved,
-                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                "traffic": traffic, "launch_ms": t_launch * 1e3, "algorithmic_flop_per_launch": flop_launch,
-                "executed_flop_per_launch": 4.0 * B * G * D}
-    log(f"[bench] in-batch: {pairs_per_s:,.0f} pairs/s, {dt / K * 1e3:.2f} ms/step, loss {loss:.4f}, "
-        f"sweep {t_launch * 1e3:.3f} ms/launch = {achieved:.1f} TFLOP/s algorithmic")
+            traffic_tab = {}
+    bgd = float(B) * G * D
+    if "inbatch_user_pass" in mean_ms:
+        # stored-G form: the user pass computes the scores once (2BGd) and dU (2BGd) and writes G; the item pass is
+        # dI = G^T.U (2BGd).  Executed = algorithmic = 6*B_neg*d per pair.
+        t_launch = mean_ms["inbatch_user_pass"] / 1e3
+        flop_launch = 4.0 * bgd
+        achieved = flop_launch / t_launch / 1e12
+        t_item = mean_ms["inbatch_item_pass"] / 1e3
+        roofline = {"bound": "mfma", "kernel": "inbatch_sweep_kernel<128,user,store-G>", "achieved": achieved,
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                    "traffic": traffic_tab.get(f"inbatch_user_pass_n{world}"), "launch_ms": t_launch * 1e3,
+                    "algorithmic_flop_per_launch": flop_launch, "executed_flop_per_launch": flop_launch,
+                    "second_kernel": {"kernel": "inbatch_gt_kernel<128>", "launch_ms": t_item * 1e3,
+                                      "algorithmic_flop_per_launch": 2.0 * bgd,
+                                      "achieved": 2.0 * bgd / t_item / 1e12,
+                                      "frac": 2.0 * bgd / t_item / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                      "traffic": traffic_tab.get(f"inbatch_item_pass_n{world}")},
+                    "loss_stage_algorithmic_tflops": 6.0 * bgd / (t_launch + t_item) / 1e12}
+        log(f"[bench] in-batch: {pairs_per_s:,.0f} pairs/s, {dt / K * 1e3:.2f} ms/step, loss {loss:.4f}, user pass "
+            f"{t_launch * 1e3:.3f} ms = {achieved:.1f} TFLOP/s, item pass {t_item * 1e3:.3f} ms = "
+            f"{2.0 * bgd / t_item / 1e12:.1f} TFLOP/s")
+    else:
+        t_launch = mean_ms.get("inbatch_sweep", 0.0) / 1e3
+        flop_launch = 3.0 * bgd                       # algorithmic: 6*B_neg*d per pair / 2 launches
+        achieved = flop_launch / t_launch / 1e12 if t_launch > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "inbatch_sweep_kernel<128>", "achieved": achieved,
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                    "traffic": traffic_tab.get(f"inbatch_sweep_n{world}"), "launch_ms": t_launch * 1e3,
+                    "algorithmic_flop_per_launch": flop_launch, "executed_flop_per_launch": 4.0 * bgd}
+        log(f"[bench] in-batch: {pairs_per_s:,.0f} pairs/s, {dt / K * 1e3:.2f} ms/step, loss {loss:.4f}, "
+            f"sweep {t_launch * 1e3:.3f} ms/launch = {achieved:.1f} TFLOP/s algorithmic")
+    flop_launch_rc = 3.0 * bgd
     secondary = {}
     if not args.no_secondary:
         # ---------------------------------------------------------- same step with the split-bf16 ("bf16x3") sweep
@@ -210,12 +235,12 @@ def main():
         tr.sweep_events = ev2
         dtb = timed(lambda i: step(W + i), K, world)
         tr.sweep_events = None
-        ms2 = [a_.elapsed_time(b_) for a_, b_ in ev2]
+        ms2 = [a_.elapsed_time(b_) for _, a_, b_ in ev2]
         tl2 = sum(ms2) / 1e3 / max(len(ms2), 1)
         secondary["inbatch_bf16x3"] = {
             "metric": "bpr_pairs_per_sec", "value": G * K / dtb, "unit": "pairs/s", "ms_per_step": dtb / K * 1e3,
             "dtype": "bf16x3 split products (hi.hi+hi.lo+lo.hi), f32 accumulate", "sweep_launch_ms": tl2 * 1e3,
-            "algorithmic_tflops": flop_launch / tl2 / 1e12 if tl2 > 0 else 0.0, "final_loss": float(tr.loss.item()),
+            "algorithmic_tflops": flop_launch_rc / tl2 / 1e12 if tl2 > 0 else 0.0, "final_loss": float(tr.loss.item()),
             "note": "optional precision mode of the dominant kernel; relative product error ~2^-16; same tests, "
                     "looser tolerance (tests/test_gpu_towers.py::test_inbatch_bf16x3_precision_mode)"}
         log(f"[bench] in-batch bf16x3: {G * K / dtb:,.0f} pairs/s, {dtb / K * 1e3:.2f} ms/step, sweep {tl2 * 1e3:.3f} ms/launch")

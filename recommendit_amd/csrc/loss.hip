@@ -77,8 +77,11 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ U
 // ------------------------------------------------------------------------------------------
 // in-batch sweep
 // ------------------------------------------------------------------------------------------
-template <int D, bool MODE_USER>
+// GOUT (user mode only): additionally write the G tile (diagonal and ragged entries = 0) to a.gmat, so that the item
+// gradients come from a plain G^T.U product (inbatch_gt_kernel) instead of a second score sweep.
+template <int D, bool MODE_USER, bool GOUT = false>
 __global__ __launch_bounds__(256, 2) void inbatch_sweep_kernel(SweepArgs a) {
+  static_assert(!GOUT || MODE_USER, "G is stored by the user-mode sweep");
   constexpr int LDY = D + 4;
   constexpr int KB = D / 8, CT = D / 32;
   constexpr int EPK = 16 / KB > 0 ? 16 / KB : 1;   // score elements processed per k-block of the next S chain
@@ -234,9 +237,12 @@ __global__ __launch_bounds__(256, 2) void inbatch_sweep_kernel(SweepArgs a) {
       }
     }
     // ---- dOwner[o][c] += sum_s G[s][o] * Y[s][c]   (A operand = g registers, k = acc_row(r))
+    float* gp = nullptr;
+    if (GOUT) gp = a.gmat + ((size_t)tile * a.g_ub + (size_t)blockIdx.x * 4 + w) * 1024 + (4 * hh) * 32 + r31;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int krow = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      if (GOUT) gp[((r & 3) + 8 * (r >> 2)) * 32] = g[r];  // 2 full 128 B lines per wave store
 #pragma unroll
       for (int t = 0; t < CT; ++t) {
         const float bv = Yc[krow * LDY + t * 32 + r31];
@@ -310,9 +316,146 @@ __global__ __launch_bounds__(256) void sweep_finish_kernel(SweepArgs a, int d) {
   reinterpret_cast<f32x4*>(a.dOwner + orow * d)[c4] = acc;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// item gradients from the stored G:  dI[j][:] = sum_i G[i][j] * U[i][:]  - r_j U_j   (plain exact-f32 GEMM)
+// owners = items (4 waves x 32 per workgroup, one 32x32 G^T block per wave and swept tile, loaded straight into the
+// MFMA A-operand registers: lane (item, hh) holds users 16*hh .. 16*hh+15 of its item = 64 contiguous bytes);
+// swept = the local users, staged through the same 3-buffer LDS pipeline as the sweep kernel.
+// ------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256, 2) void inbatch_gt_kernel(SweepArgs a) {
+  constexpr int LDY = D + 4;
+  constexpr int CT = D / 32;
+  constexpr int NV = (TSW * (D / 4) + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float Ysh[3][TSW * LDY];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r31 = lane & 31, hh = lane >> 5;
+  const int64_t o_base = (int64_t)blockIdx.x * OW + w * 32;
+
+  f32x16 out[CT];
+#pragma unroll
+  for (int t = 0; t < CT; ++t) out[t] = zero16();
+
+  const int64_t ntiles = (a.Ns + TSW - 1) / TSW;
+  const int64_t per = (ntiles + a.nsplit - 1) / a.nsplit;
+  const int64_t t0 = (int64_t)blockIdx.y * per;
+  const int64_t t1 = (t0 + per < ntiles) ? t0 + per : ntiles;
+
+  f32x4 stage[NV];
+  auto load_tile = [&](int64_t tile) {
+    const int64_t s_base = tile * TSW;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * 256;
+      const int r = idx / (D / 4), c4 = idx % (D / 4);
+      const int64_t srow = s_base + r;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (idx < TSW * (D / 4) && srow < a.Ns) v = reinterpret_cast<const f32x4*>(a.Ys + srow * D)[c4];
+      stage[i] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * 256;
+      const int r = idx / (D / 4), c4 = idx % (D / 4);
+      if (idx < TSW * (D / 4)) *reinterpret_cast<f32x4*>(&Ysh[buf][r * LDY + c4 * 4]) = stage[i];
+    }
+  };
+  // this wave's G^T block row; consecutive swept tiles are consecutive 4 KB blocks
+  const f32x4* gp = reinterpret_cast<const f32x4*>(a.gmat + ((size_t)(blockIdx.x * 4 + w) * a.g_ub) * 1024 +
+                                                   r31 * 32 + 16 * hh);
+  f32x4 gc[4], gn[4], gq[4];  // G of tile, tile+1, tile+2
+#pragma unroll
+  for (int q = 0; q < 4; ++q) gc[q] = gn[q] = gq[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (t0 < t1) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gc[q] = gp[(size_t)t0 * 256 + q];
+    load_tile(t0);
+    store_tile(0);
+    if (t0 + 1 < t1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gn[q] = gp[(size_t)(t0 + 1) * 256 + q];
+      load_tile(t0 + 1);
+      store_tile(1);
+    }
+    __syncthreads();
+  }
+#pragma unroll 1
+  for (int64_t tile = t0; tile < t1; ++tile) {
+    const int it = (int)((tile - t0) % 3);
+    const int cur = it, pre = (it + 2) % 3;
+    const bool has_pre = (tile + 2 < t1);
+    if (has_pre) {
+      load_tile(tile + 2);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gq[q] = gp[(size_t)(tile + 2) * 256 + q];
+    }
+    const float* Yc = Ysh[cur];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int krow = 16 * hh + 4 * q + s;
+#pragma unroll
+        for (int t = 0; t < CT; ++t) out[t] = mfma32(gc[q][s], Yc[krow * LDY + t * 32 + r31], out[t]);
+      }
+    }
+    if (has_pre) store_tile(pre);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      gc[q] = gn[q];
+      gn[q] = gq[q];
+    }
+    __syncthreads();
+  }
+
+  const bool final_pass = (a.nsplit == 1);
+  float* dst = final_pass ? a.dOwner : a.slab + (size_t)blockIdx.y * a.No * D;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t orow = o_base + acc_row(r, lane);
+    if (orow < a.No) {
+      const int64_t drow = a.o_goff + orow - a.s_goff;  // the item's own user inside the swept (local) users
+      const bool fix = final_pass && drow >= 0 && drow < a.Ns;
+      const float rs = fix ? a.r_in[drow] : 0.f;
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+        float v = out[t][r];
+        if (fix) v -= rs * a.Ys[drow * D + t * 32 + r31];  // G_jj = -r_j
+        dst[orow * D + t * 32 + r31] = v;
+      }
+    }
+  }
+}
+
+// nsplit>1 finish of the stored-G item pass: dOwner = sum_s slab[s] - r * U[diag]   (fixed order)
+__global__ __launch_bounds__(256) void gt_finish_kernel(SweepArgs a, int d) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int v4 = d / 4;
+  if (i >= a.No * v4) return;
+  const int64_t orow = i / v4;
+  const int c4 = (int)(i % v4);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < a.nsplit; ++s) {
+    const f32x4 u = reinterpret_cast<const f32x4*>(a.slab + ((size_t)s * a.No + orow) * d)[c4];
+    acc.x += u.x; acc.y += u.y; acc.z += u.z; acc.w += u.w;
+  }
+  const int64_t drow = a.o_goff + orow - a.s_goff;
+  if (drow >= 0 && drow < a.Ns) {
+    const float rs = a.r_in[drow];
+    const f32x4 y = reinterpret_cast<const f32x4*>(a.Ys + drow * d)[c4];
+    acc.x -= rs * y.x; acc.y -= rs * y.y; acc.z -= rs * y.z; acc.w -= rs * y.w;
+  }
+  reinterpret_cast<f32x4*>(a.dOwner + orow * d)[c4] = acc;
+}
+
 template <int D>
 void launch_sweep(bool mode_user, const SweepArgs& a, dim3 grid, hipStream_t st) {
-  if (mode_user) hipLaunchKernelGGL((inbatch_sweep_kernel<D, true>), grid, dim3(256), 0, st, a);
+  if (mode_user && a.gmat) hipLaunchKernelGGL((inbatch_sweep_kernel<D, true, true>), grid, dim3(256), 0, st, a);
+  else if (mode_user) hipLaunchKernelGGL((inbatch_sweep_kernel<D, true>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((inbatch_sweep_kernel<D, false>), grid, dim3(256), 0, st, a);
 }
 
@@ -380,6 +523,7 @@ extern "C" int rihip_inbatch_sweep(int mode_user, const float* owners, int64_t n
   a.Xo = owners; a.No = n_owner; a.o_goff = owner_goff; a.Ys = swept; a.Ns = n_swept; a.s_goff = swept_goff;
   a.pos = pos; a.r_in = r_in; a.c = (float)(1.0 / ((double)n_global * (double)(n_global - 1)));
   a.dOwner = d_owner; a.r_out = r_out; a.loss_part = loss_part;
+  a.gmat = nullptr; a.g_ub = 0;
   a.nsplit = sweep_nsplit(n_owner, n_swept);
   RIHIP_REQUIRE(a.nsplit == 1 || workspace, RIHIP_ERR_ARG, "inbatch_sweep: workspace required (nsplit=%d)", a.nsplit);
   a.slab = workspace;
@@ -395,6 +539,73 @@ extern "C" int rihip_inbatch_sweep(int mode_user, const float* owners, int64_t n
     const int64_t n4 = n_owner * (d / 4);
     if (mode_user) hipLaunchKernelGGL((sweep_finish_kernel<true>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, a, d);
     else hipLaunchKernelGGL((sweep_finish_kernel<false>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, a, d);
+    RIHIP_CHECK_LAUNCH();
+  }
+  return RIHIP_OK;
+}
+
+// ---- stored-G variant: user pass writes G, item pass is a plain G^T.U product --------------------------------------
+extern "C" int64_t rihip_inbatch_gmat_floats(int64_t n_users, int64_t n_items) {
+  const int64_t ub = 4 * ((n_users + OW - 1) / OW), ib = 4 * ((n_items + OW - 1) / OW);
+  return ub * ib * 1024;
+}
+
+extern "C" int rihip_inbatch_user_pass(const float* users, int64_t n_users, int64_t user_goff, const float* items,
+                                       int64_t n_items, int64_t item_goff, int d, const float* pos, int64_t n_global,
+                                       float* d_users, float* r_out, double* loss_part, float* workspace, float* gmat,
+                                       void* stream) {
+  RIHIP_REQUIRE(d == 32 || d == 64 || d == 128, RIHIP_ERR_SHAPE, "inbatch_user_pass: unsupported embed_dim=%d", d);
+  RIHIP_REQUIRE(users && items && pos && d_users && r_out && loss_part && gmat, RIHIP_ERR_ARG,
+                "inbatch_user_pass: null pointer");
+  RIHIP_REQUIRE(n_users > 0 && n_items > 0 && n_global >= 2, RIHIP_ERR_ARG,
+                "inbatch_user_pass: sizes users=%lld items=%lld B=%lld", (long long)n_users, (long long)n_items,
+                (long long)n_global);
+  SweepArgs a;
+  a.Xo = users; a.No = n_users; a.o_goff = user_goff; a.Ys = items; a.Ns = n_items; a.s_goff = item_goff;
+  a.pos = pos; a.r_in = nullptr; a.c = (float)(1.0 / ((double)n_global * (double)(n_global - 1)));
+  a.dOwner = d_users; a.r_out = r_out; a.loss_part = loss_part;
+  a.gmat = gmat; a.g_ub = 4 * ((n_users + OW - 1) / OW);
+  a.nsplit = sweep_nsplit(n_users, n_items);
+  RIHIP_REQUIRE(a.nsplit == 1 || workspace, RIHIP_ERR_ARG, "inbatch_user_pass: workspace required (nsplit=%d)", a.nsplit);
+  a.slab = workspace;
+  a.r_part = workspace ? workspace + (size_t)a.nsplit * n_users * d : nullptr;
+  const dim3 grid((unsigned)((n_users + OW - 1) / OW), (unsigned)a.nsplit);
+  hipStream_t st = (hipStream_t)stream;
+  if (d == 32) launch_sweep<32>(true, a, grid, st);
+  else if (d == 64) launch_sweep<64>(true, a, grid, st);
+  else launch_sweep<128>(true, a, grid, st);
+  RIHIP_CHECK_LAUNCH();
+  if (a.nsplit > 1) {
+    const int64_t n4 = n_users * (d / 4);
+    hipLaunchKernelGGL((sweep_finish_kernel<true>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, a, d);
+    RIHIP_CHECK_LAUNCH();
+  }
+  return RIHIP_OK;
+}
+
+extern "C" int rihip_inbatch_item_pass(const float* gmat, const float* users, int64_t n_users, int64_t user_goff,
+                                       int64_t n_items, int64_t item_goff, int d, const float* r, float* d_items,
+                                       float* workspace, void* stream) {
+  RIHIP_REQUIRE(d == 32 || d == 64 || d == 128, RIHIP_ERR_SHAPE, "inbatch_item_pass: unsupported embed_dim=%d", d);
+  RIHIP_REQUIRE(gmat && users && r && d_items, RIHIP_ERR_ARG, "inbatch_item_pass: null pointer");
+  RIHIP_REQUIRE(n_users > 0 && n_items > 0, RIHIP_ERR_ARG, "inbatch_item_pass: sizes users=%lld items=%lld",
+                (long long)n_users, (long long)n_items);
+  SweepArgs a;
+  a.Xo = nullptr; a.No = n_items; a.o_goff = item_goff; a.Ys = users; a.Ns = n_users; a.s_goff = user_goff;
+  a.pos = nullptr; a.r_in = r; a.c = 0.f; a.dOwner = d_items; a.r_out = nullptr; a.loss_part = nullptr;
+  a.gmat = const_cast<float*>(gmat); a.g_ub = 4 * ((n_users + OW - 1) / OW);
+  a.nsplit = sweep_nsplit(n_items, n_users);
+  RIHIP_REQUIRE(a.nsplit == 1 || workspace, RIHIP_ERR_ARG, "inbatch_item_pass: workspace required (nsplit=%d)", a.nsplit);
+  a.slab = workspace; a.r_part = nullptr;
+  const dim3 grid((unsigned)((n_items + OW - 1) / OW), (unsigned)a.nsplit);
+  hipStream_t st = (hipStream_t)stream;
+  if (d == 32) hipLaunchKernelGGL((inbatch_gt_kernel<32>), grid, dim3(256), 0, st, a);
+  else if (d == 64) hipLaunchKernelGGL((inbatch_gt_kernel<64>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((inbatch_gt_kernel<128>), grid, dim3(256), 0, st, a);
+  RIHIP_CHECK_LAUNCH();
+  if (a.nsplit > 1) {
+    const int64_t n4 = n_items * (d / 4);
+    hipLaunchKernelGGL(gt_finish_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, a, d);
     RIHIP_CHECK_LAUNCH();
   }
   return RIHIP_OK;

@@ -18,6 +18,8 @@ struct SweepArgs {
   float* slab;       // nsplit>1: [nsplit][No][d] partial owner gradients
   float* r_part;     // nsplit>1, MODE_USER: [nsplit][No]
   int nsplit;
+  float* gmat;       // stored-G variant: G^T in 32x32 blocks, block (item_blk, user_blk) at (item_blk*g_ub + user_blk)*1024,
+  int64_t g_ub;      //   element (item_local, user_local) at item_local*32 + user_local ; g_ub = user blocks per item block row
 };
 
 constexpr int OW = 128;  // owners per workgroup (32 per wave)

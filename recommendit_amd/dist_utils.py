@@ -51,3 +51,16 @@ def all_reduce_sum_(t: torch.Tensor, group=None) -> None:
         t.copy_(c.to(t.device))
     else:
         dist.all_reduce(t, group=group)
+
+
+def reduce_scatter_sum(out: torch.Tensor, inp: torch.Tensor, group=None, async_op: bool = False):
+    """out = (sum over ranks of inp)[rank*n:(rank+1)*n], n = out.shape[0] (rows).  Same async contract as
+    all_gather_into."""
+    if inp.is_cuda and not _staged(inp, group):
+        w = dist.reduce_scatter_tensor(out, inp.contiguous(), group=group, async_op=async_op)
+        return w if async_op else _Done()
+    c = inp.detach().cpu().contiguous()          # gloo has no reduce_scatter: all-reduce on the host, keep own slice
+    dist.all_reduce(c, group=group)
+    r, n = dist.get_rank(group), out.shape[0]
+    out.copy_(c[r * n:(r + 1) * n].to(out.device))
+    return _Done()

@@ -28,7 +28,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib as L
-from .dist_utils import all_gather_into, all_reduce_sum_
+from .dist_utils import all_gather_into, all_reduce_sum_, reduce_scatter_sum
 from .two_tower import TwoTowerModel
 
 _MLP_KEYS = ["user_tower.mlp.0.weight", "user_tower.mlp.0.bias", "user_tower.mlp.3.weight", "user_tower.mlp.3.bias",
@@ -97,7 +97,7 @@ class HipBPRTrainer:
     def __init__(self, model: TwoTowerModel, batch_size: int, lr: float = 1e-3, weight_decay: float = 1e-5,
                  betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = 1.0, loss_mode: str = "sampled",
                  table_opt: str = "dense", seed: int = 0, process_group=None, user_row_offset: int = 0,
-                 inbatch_precision: int = 0, use_graph: bool = False):
+                 inbatch_precision: int = 0, use_graph: bool = False, inbatch_store_g=None):
         assert loss_mode in ("sampled", "inbatch") and table_opt in ("dense", "sparse")
         self.lib = L.lib()
         self.model = model
@@ -108,9 +108,11 @@ class HipBPRTrainer:
         self.step_count = 0
         self.seed = seed
         self.inbatch_precision = int(inbatch_precision)  # 0 = exact f32 MFMA, 1 = split-bf16 (bf16x3)
+        self.inbatch_store_g = inbatch_store_g  # None = auto: store G (no second score sweep) when it fits in HBM
         self.sweep_events = None
         self.use_graph = bool(use_graph)
         self._graph = None
+        self._dI_work = None
         self._eager_steps = 0  # bench hook: list collecting (start, end) events around every sweep launch
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
@@ -178,14 +180,28 @@ class HipBPRTrainer:
         self.lpart = torch.zeros((max(1024, self.lib.rihip_inbatch_workspace_doubles(B)),), dtype=torch.float64,
                                  device=self.dev)
         Gall = B * (self.world if self.world > 1 else 1)
-        self.sws = torch.empty((self.lib.rihip_inbatch_workspace_floats(B, Gall, d),), **f32)
+        self.sws = torch.empty((max(self.lib.rihip_inbatch_workspace_floats(B, Gall, d),
+                                    self.lib.rihip_inbatch_workspace_floats(Gall, B, d)),), **f32)
         self.n_lparts = self.lib.rihip_inbatch_loss_parts(B, Gall)
+        self.gmat = None
         if loss_mode == "inbatch":
             self.pos = torch.empty((B,), **f32); self.r = torch.empty((B,), **f32)
+            # stored-G form (exact f32 only): G^T of the local users x all items stays in HBM between the two passes
+            # (17 GB at B = 65536 on one GPU, 2 GB per rank on eight) and removes the second score sweep
+            ng = self.lib.rihip_inbatch_gmat_floats(B, Gall)
+            store = self.inbatch_store_g
+            if store is None:
+                free_b = torch.cuda.mem_get_info(self.dev)[0]
+                store = self.inbatch_precision == 0 and 4 * ng <= 0.5 * free_b
+            self.inbatch_store_g = bool(store) and self.inbatch_precision == 0
+            if self.inbatch_store_g:
+                self.gmat = torch.empty((ng,), **f32)
             if self.world > 1:
                 W = self.world
-                self.U_all = torch.empty((W * B, d), **f32); self.I_all = torch.empty((W * B, d), **f32)
-                self.pos_all = torch.empty((W * B,), **f32); self.r_all = torch.empty((W * B,), **f32)
+                self.I_all = torch.empty((W * B, d), **f32)
+                if self.inbatch_store_g:
+                    self.dI_all = torch.empty((W * B, d), **f32)
+                self.U_all = None  # recompute form only: allocated on first use
         if self.world > 1:
             W = self.world
             self.iid_all = torch.empty((W * nI,), dtype=torch.int64, device=self.dev)
@@ -265,18 +281,20 @@ class HipBPRTrainer:
         else:
             self._inbatch(st)
 
-        # item tower first: its row gradients travel (all-gather) while the user tower's backward runs
-        self._bwd(self.itab, item_ids, item_genres, ikeys, self.dI, self.I, self.denI, self.hidI, self.dXi)
-        iid, dXi = item_ids, self.dXi
-        if self.world > 1:
-            w_i = all_gather_into(self.iid_all, item_ids, self.pg, async_op=True)
-            w_x = all_gather_into(self.dXi_all, self.dXi, self.pg, async_op=True)
+        # user tower first: in the multi-GPU stored-G form dI is still being reduce-scattered
         self._bwd(self.utab, user_ids, None, ukeys, self.dU, self.U, self.denU, self.hidU, self.dXu)
+        if self._dI_work is not None:
+            self._dI_work.wait(); self._dI_work = None
+        self._bwd(self.itab, item_ids, item_genres, ikeys, self.dI, self.I, self.denI, self.hidI, self.dXi)
 
         # ---- gradient exchange (multi-GPU) + global grad norm -> clip coef (device scalar)
+        iid, dXi = item_ids, self.dXi
+        w_i = w_x = None
         if self.world > 1:
+            # the item row gradients travel while the MLP all-reduce and the user-row grouping run
+            w_i = all_gather_into(self.iid_all, item_ids, self.pg, async_op=True)
+            w_x = all_gather_into(self.dXi_all, self.dXi, self.pg, async_op=True)
             all_reduce_sum_(self.flat_g, self.pg)
-            w_i.wait(); w_x.wait()
             iid, dXi = self.iid_all, self.dXi_all
         pp = self.part.data_ptr()
         L.check(lib.rihip_sumsq(self.flat_g.data_ptr(), self.flat_g.numel(), pp, st), "sumsq")
@@ -284,6 +302,8 @@ class HipBPRTrainer:
         o2 = o1 + self.np_rows
         if self.table_opt == "sparse":
             self.uopt.group_reduce(user_ids, self.dXu, pp + 8 * o1, st)
+            if w_i is not None:
+                w_i.wait(); w_x.wait()
             self.iopt.group_reduce(iid, dXi, pp + 8 * o2, st)
         else:
             self.uopt.scatter(user_ids, self.dXu, st); self.uopt.sumsq(pp + 8 * o1, st)
@@ -307,48 +327,67 @@ class HipBPRTrainer:
         self.iopt.adam(lr, self.b1, self.b2, self.eps, self.wd, t, cp, st, hp)
         return self.loss
 
-    def _sweep(self, *args) -> None:
+    def _timed(self, fn, what, *args) -> None:
         ev = self.sweep_events
         if ev is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        L.check(self.lib.rihip_inbatch_sweep(*args), "inbatch_sweep")
+        L.check(fn(*args), what)
         if ev is not None:
             e1.record()
-            ev.append((e0, e1))
+            ev.append((what, e0, e1))
+
+    def _sweep(self, *args) -> None:
+        self._timed(self.lib.rihip_inbatch_sweep, "inbatch_sweep", *args)
 
     def _inbatch(self, st: int) -> None:
         lib, B, d, W = self.lib, self.B, self.d, self.world
-        if W == 1:
-            L.check(lib.rihip_rowdot(self.U.data_ptr(), self.I.data_ptr(), B, 0, d, self.pos.data_ptr(), st), "rowdot")
+        G, off = W * B, self.rank * B
+        L.check(lib.rihip_rowdot(self.U.data_ptr(), self.I.data_ptr(), B, 0, d, self.pos.data_ptr(), st), "rowdot")
+        I_all = self.I
+        if W > 1:
+            # global in-batch negatives: every rank scores its users against ALL items (4 MiB/rank at B=8192, d=128)
+            all_gather_into(self.I_all, self.I, self.pg)
+            I_all = self.I_all
+        if self.inbatch_store_g and self.inbatch_precision == 0:
+            # user pass keeps G in HBM; item pass = G^T.U over the local users for all items, reduce-scattered to
+            # the rank that owns each item's tower backward (no second score sweep, no U/pos/r gathers)
+            self._timed(lib.rihip_inbatch_user_pass, "inbatch_user_pass", self.U.data_ptr(), B, off, I_all.data_ptr(),
+                        G, 0, d, self.pos.data_ptr(), G, self.dU.data_ptr(), self.r.data_ptr(), self.lpart.data_ptr(),
+                        self.sws.data_ptr(), self.gmat.data_ptr(), st)
+            dI_all = self.dI if W == 1 else self.dI_all
+            self._timed(lib.rihip_inbatch_item_pass, "inbatch_item_pass", self.gmat.data_ptr(), self.U.data_ptr(), B,
+                        off, G, 0, d, self.r.data_ptr(), dI_all.data_ptr(), self.sws.data_ptr(), st)
+            if W > 1:
+                self._dI_work = reduce_scatter_sum(self.dI, self.dI_all, self.pg, async_op=True)
+        elif W == 1:
             self._sweep(1, self.U.data_ptr(), B, 0, self.I.data_ptr(), B, 0, d,
                                             self.pos.data_ptr(), None, B, self.dU.data_ptr(), self.r.data_ptr(),
                                             self.lpart.data_ptr(), self.sws.data_ptr(), self.inbatch_precision, st)
             self._sweep(0, self.I.data_ptr(), B, 0, self.U.data_ptr(), B, 0, d,
                                             self.pos.data_ptr(), self.r.data_ptr(), B, self.dI.data_ptr(), None,
                                             None, self.sws.data_ptr(), self.inbatch_precision, st)
-            L.check(lib.rihip_sum_partials(self.lpart.data_ptr(), self.n_lparts, 1.0 / (B * (B - 1.0)),
-                                           self.loss.data_ptr(), st), "sum_partials")
-            return
-        # global in-batch negatives: all-gather both towers' outputs (4 MiB/rank at B=8192, d=128), then each rank
-        # sweeps its own users against ALL items and its own items against ALL users (no reduce-scatter).
-        G, off = W * B, self.rank * B
-        L.check(lib.rihip_rowdot(self.U.data_ptr(), self.I.data_ptr(), B, 0, d, self.pos.data_ptr(), st), "rowdot")
-        all_gather_into(self.I_all, self.I, self.pg)
-        # U_all / pos_all are only read by the item-mode sweep: they travel under the user-mode sweep
-        w_u = all_gather_into(self.U_all, self.U, self.pg, async_op=True)
-        w_p = all_gather_into(self.pos_all, self.pos, self.pg, async_op=True)
-        self._sweep(1, self.U.data_ptr(), B, off, self.I_all.data_ptr(), G, 0, d,
-                                        self.pos.data_ptr(), None, G, self.dU.data_ptr(), self.r.data_ptr(),
-                                        self.lpart.data_ptr(), self.sws.data_ptr(), self.inbatch_precision, st)
-        all_gather_into(self.r_all, self.r, self.pg)
-        w_u.wait(); w_p.wait()
-        self._sweep(0, self.I.data_ptr(), B, off, self.U_all.data_ptr(), G, 0, d,
-                                        self.pos_all.data_ptr(), self.r_all.data_ptr(), G, self.dI.data_ptr(), None,
-                                        None, self.sws.data_ptr(), self.inbatch_precision, st)
+        else:
+            # recompute form: each rank sweeps its own items against ALL users
+            if self.U_all is None:
+                f32 = dict(dtype=torch.float32, device=self.dev)
+                self.U_all = torch.empty((G, d), **f32)
+                self.pos_all = torch.empty((G,), **f32); self.r_all = torch.empty((G,), **f32)
+            # U_all / pos_all are only read by the item-mode sweep: they travel under the user-mode sweep
+            w_u = all_gather_into(self.U_all, self.U, self.pg, async_op=True)
+            w_p = all_gather_into(self.pos_all, self.pos, self.pg, async_op=True)
+            self._sweep(1, self.U.data_ptr(), B, off, self.I_all.data_ptr(), G, 0, d,
+                                            self.pos.data_ptr(), None, G, self.dU.data_ptr(), self.r.data_ptr(),
+                                            self.lpart.data_ptr(), self.sws.data_ptr(), self.inbatch_precision, st)
+            all_gather_into(self.r_all, self.r, self.pg)
+            w_u.wait(); w_p.wait()
+            self._sweep(0, self.I.data_ptr(), B, off, self.U_all.data_ptr(), G, 0, d,
+                                            self.pos_all.data_ptr(), self.r_all.data_ptr(), G, self.dI.data_ptr(), None,
+                                            None, self.sws.data_ptr(), self.inbatch_precision, st)
         L.check(lib.rihip_sum_partials(self.lpart.data_ptr(), self.n_lparts, 1.0 / (G * (G - 1.0)),
                                        self.loss.data_ptr(), st), "sum_partials")
-        all_reduce_sum_(self.loss, self.pg)
+        if W > 1:
+            all_reduce_sum_(self.loss, self.pg)
 
 
 def cosine_lr(lr0: float, epoch: int, t_max: int) -> float:

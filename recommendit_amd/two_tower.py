@@ -185,8 +185,10 @@ class _BprPairFn(torch.autograd.Function):
 def inbatch_loss_and_grads(U: torch.Tensor, I: torch.Tensor, precision: int = 0, owner_offset: int = 0,
                            n_global: Optional[int] = None, pos: Optional[torch.Tensor] = None,
                            r: Optional[torch.Tensor] = None, users_global: Optional[torch.Tensor] = None,
-                           item_owner_offset: Optional[int] = None):
-    """Single-GPU closed-form in-batch BPR: returns (loss, dU, dI) for square U,I [B,d]."""
+                           item_owner_offset: Optional[int] = None, store_g: Optional[bool] = None):
+    """Single-GPU closed-form in-batch BPR: returns (loss, dU, dI) for square U,I [B,d].
+    store_g (exact f32 only; default: on while the B x B matrix stays under 4 GiB): the user pass keeps G in HBM and
+    dI is a plain G^T.U product instead of a second score sweep."""
     lib = L.lib()
     dev = L.device()
     Uc, Ic = L.f32c(U), L.f32c(I)
@@ -199,6 +201,19 @@ def inbatch_loss_and_grads(U: torch.Tensor, I: torch.Tensor, precision: int = 0,
     part = torch.zeros((lib.rihip_inbatch_workspace_doubles(B),), dtype=torch.float64, device=dev)
     ws = torch.empty((lib.rihip_inbatch_workspace_floats(B, B, d),), dtype=torch.float32, device=dev)
     loss = torch.empty((), dtype=torch.float32, device=dev)
+    ng = lib.rihip_inbatch_gmat_floats(B, B)
+    if store_g is None:
+        store_g = 4 * ng <= (4 << 30)
+    if store_g and precision == 0:
+        gm = torch.empty((ng,), dtype=torch.float32, device=dev)
+        L.check(lib.rihip_inbatch_user_pass(Uc.data_ptr(), B, 0, Ic.data_ptr(), B, 0, d, posv.data_ptr(), B,
+                                            dU.data_ptr(), rv.data_ptr(), part.data_ptr(), ws.data_ptr(),
+                                            gm.data_ptr(), st), "inbatch_user_pass")
+        L.check(lib.rihip_inbatch_item_pass(gm.data_ptr(), Uc.data_ptr(), B, 0, B, 0, d, rv.data_ptr(), dI.data_ptr(),
+                                            ws.data_ptr(), st), "inbatch_item_pass")
+        L.check(lib.rihip_sum_partials(part.data_ptr(), lib.rihip_inbatch_loss_parts(B, B), 1.0 / (B * (B - 1.0)),
+                                       loss.data_ptr(), st), "sum_partials")
+        return loss, dU, dI
     L.check(lib.rihip_inbatch_sweep(1, Uc.data_ptr(), B, 0, Ic.data_ptr(), B, 0, d, posv.data_ptr(), None, B,
                                     dU.data_ptr(), rv.data_ptr(), part.data_ptr(), ws.data_ptr(), precision, st),
             "inbatch_sweep(user)")

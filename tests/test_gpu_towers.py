@@ -178,6 +178,50 @@ def test_inbatch_vs_oracle_ragged_and_reproducible(B, d):
     np.testing.assert_allclose(dI1.cpu().numpy(), dIo, atol=3e-9, rtol=3e-4)
 
 
+@pytest.mark.parametrize("B,d", [(33, 32), (257, 64), (500, 128)])
+def test_inbatch_stored_g_equals_recompute_form(B, d):
+    """The stored-G form (user pass writes G, item pass = G^T.U) and the two-sweep form give the same dU/r bit for
+    bit and the same dI up to f32 summation order; both agree with the oracle."""
+    from recommendit_amd.two_tower import inbatch_loss_and_grads
+    rng = np.random.RandomState(B + 1)
+    U, I = fx.unit_rows(rng, B, d), fx.unit_rows(rng, B, d)
+    l1, dU1, dI1 = inbatch_loss_and_grads(t(U), t(I), store_g=True)
+    l2, dU2, dI2 = inbatch_loss_and_grads(t(U), t(I), store_g=False)
+    assert torch.equal(l1, l2) and torch.equal(dU1, dU2)
+    np.testing.assert_allclose(dI1.cpu().numpy(), dI2.cpu().numpy(), atol=1e-9, rtol=2e-5)
+    _, _, dIo = O.in_batch_bpr_loss(U, I)
+    np.testing.assert_allclose(dI1.cpu().numpy(), dIo, atol=3e-9, rtol=3e-4)
+
+
+@pytest.mark.parametrize("Bl,G,off,d", [(100, 300, 100, 64), (64, 256, 192, 128), (37, 111, 0, 32)])
+def test_inbatch_stored_g_rectangular_rank_form(Bl, G, off, d):
+    """Multi-GPU shape of the stored-G passes through the C ABI: local users [Bl] (positives = items off..off+Bl)
+    against all G items; the item pass returns this rank's partial dI for ALL items (oracle: rectangular form)."""
+    from recommendit_amd import _lib as L
+    lib, dev, st = L.lib(), L.device(), L.stream_ptr()
+    rng = np.random.RandomState(Bl)
+    U, I = fx.unit_rows(rng, Bl, d), fx.unit_rows(rng, G, d)
+    Ud, Id = t(U).to(dev).contiguous(), t(I).to(dev).contiguous()
+    f32 = dict(dtype=torch.float32, device=dev)
+    pos = torch.empty(Bl, **f32); r = torch.empty(Bl, **f32)
+    dU = torch.empty(Bl, d, **f32); dI = torch.full((G, d), float("nan"), **f32)
+    lp = torch.zeros(max(1024, lib.rihip_inbatch_workspace_doubles(Bl)), dtype=torch.float64, device=dev)
+    ws = torch.empty(max(lib.rihip_inbatch_workspace_floats(Bl, G, d), lib.rihip_inbatch_workspace_floats(G, Bl, d)), **f32)
+    gm = torch.full((lib.rihip_inbatch_gmat_floats(Bl, G),), float("nan"), **f32)   # unwritten blocks must not leak
+    loss = torch.empty((), **f32)
+    L.check(lib.rihip_rowdot(Ud.data_ptr(), Id.data_ptr(), Bl, off, d, pos.data_ptr(), st), "rowdot")
+    L.check(lib.rihip_inbatch_user_pass(Ud.data_ptr(), Bl, off, Id.data_ptr(), G, 0, d, pos.data_ptr(), G,
+                                        dU.data_ptr(), r.data_ptr(), lp.data_ptr(), ws.data_ptr(), gm.data_ptr(), st), "up")
+    L.check(lib.rihip_inbatch_item_pass(gm.data_ptr(), Ud.data_ptr(), Bl, off, G, 0, d, r.data_ptr(), dI.data_ptr(),
+                                        ws.data_ptr(), st), "ip")
+    L.check(lib.rihip_sum_partials(lp.data_ptr(), lib.rihip_inbatch_loss_parts(Bl, G), 1.0 / (G * (G - 1.0)),
+                                   loss.data_ptr(), st), "sum")
+    lo, dUo, dIo = O.in_batch_bpr_loss(U, I, owner_offset=off, n_global=G)
+    assert abs(loss.item() - float(lo)) < 3e-6
+    np.testing.assert_allclose(dU.cpu().numpy(), dUo, atol=3e-9, rtol=3e-4)
+    np.testing.assert_allclose(dI.cpu().numpy(), dIo, atol=3e-9, rtol=3e-4)
+
+
 def test_inbatch_full_size_properties():
     """cfg2 size (B=8192, d=64): size-independent properties instead of the O(B^2) oracle:
     sum_i dU_i . u_i + ... identities: d loss/d(scale) -- here: gradient of a loss that only depends on
