@@ -9,6 +9,7 @@
 //    no LDS round trip).  Owner gradients never cross workgroups => no atomics, bitwise
 //    reproducible.  dU and dI come from two launches of the same kernel with roles swapped
 //    (S is recomputed; 8 B^2 d FLOP instead of 6 B^2 d, but zero atomic traffic).
+#include <stdlib.h>
 #include "common.h"
 #include "recommendit_hip.h"
 #include "loss_sweep_args.h"
@@ -79,23 +80,24 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ U
 // ------------------------------------------------------------------------------------------
 // GOUT (user mode only): additionally write the G tile (diagonal and ragged entries = 0) to a.gmat, so that the item
 // gradients come from a plain G^T.U product (inbatch_gt_kernel) instead of a second score sweep.
-template <int D, bool MODE_USER, bool GOUT = false>
-__global__ __launch_bounds__(256, 2) void inbatch_sweep_kernel(SweepArgs a) {
+template <int D, bool MODE_USER, bool GOUT = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64, 2) void inbatch_sweep_kernel(SweepArgs a) {
+  constexpr int NT = NW * 64;  // NW = 8: one 512-thread workgroup per CU, half the swept-tile traffic per owner
   static_assert(!GOUT || MODE_USER, "G is stored by the user-mode sweep");
   constexpr int LDY = D + 4;
   constexpr int KB = D / 8, CT = D / 32;
   constexpr int EPK = 16 / KB > 0 ? 16 / KB : 1;   // score elements processed per k-block of the next S chain
-  constexpr int NV = (TSW * (D / 4) + 255) / 256;  // float4 staged per thread per tile
+  constexpr int NV = (TSW * (D / 4) + NT - 1) / NT;  // float4 staged per thread per tile
   static_assert(KB <= 16, "embed_dim <= 128");
   __shared__ __attribute__((aligned(16))) float Ysh[3][TSW * LDY];
   __shared__ float posS[3][TSW];
   __shared__ float rS[3][TSW];
-  __shared__ float rsum[4][32];
-  __shared__ double red_loss[4];
+  __shared__ float rsum[NW][32];
+  __shared__ double red_loss[NW];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r31 = lane & 31, hh = lane >> 5;
-  const int64_t o_base = (int64_t)blockIdx.x * OW + w * 32;
+  const int64_t o_base = (int64_t)blockIdx.x * (NW * 32) + w * 32;
   const int64_t o_loc = o_base + r31;  // this lane's owner (S^T accumulator column)
   const bool o_ok = o_loc < a.No;
   const int64_t o_gidx = a.o_goff + o_loc;
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void inbatch_sweep_kernel(SweepArgs a) {
     const int64_t s_base = tile * TSW;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int idx = tid + i * 256;
+      const int idx = tid + i * NT;
       const int r = idx / (D / 4), c4 = idx % (D / 4);
       const int64_t srow = s_base + r;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void inbatch_sweep_kernel(SweepArgs a) {
   auto store_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int idx = tid + i * 256;
+      const int idx = tid + i * NT;
       const int r = idx / (D / 4), c4 = idx % (D / 4);
       if (idx < TSW * (D / 4)) *reinterpret_cast<f32x4*>(&Ysh[buf][r * LDY + c4 * 4]) = stage[i];
     }
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void inbatch_sweep_kernel(SweepArgs a) {
     }
     // ---- dOwner[o][c] += sum_s G[s][o] * Y[s][c]   (A operand = g registers, k = acc_row(r))
     float* gp = nullptr;
-    if (GOUT) gp = a.gmat + ((size_t)tile * a.g_ub + (size_t)blockIdx.x * 4 + w) * 1024 + (4 * hh) * 32 + r31;
+    if (GOUT) gp = a.gmat + ((size_t)tile * a.g_ub + (size_t)blockIdx.x * NW + w) * 1024 + (4 * hh) * 32 + r31;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int krow = (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -286,8 +288,14 @@ __global__ __launch_bounds__(256, 2) void inbatch_sweep_kernel(SweepArgs a) {
     if (final_pass) a.r_out[o_loc] = rsum[w][r31];
     else a.r_part[(size_t)blockIdx.y * a.No + o_loc] = rsum[w][r31];
   }
-  if (MODE_USER && tid == 0)
-    a.loss_part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = ((red_loss[0] + red_loss[1]) + red_loss[2]) + red_loss[3];
+  // loss partials keep the 128-owner granularity of rihip_inbatch_loss_parts() whatever the workgroup size
+  if (MODE_USER && tid < NW / 4) {
+    const int64_t gx128 = (a.No + OW - 1) / OW;
+    const int64_t slot = (int64_t)blockIdx.x * (NW / 4) + tid;
+    if (slot < gx128)
+      a.loss_part[(size_t)blockIdx.y * gx128 + slot] =
+          ((red_loss[4 * tid] + red_loss[4 * tid + 1]) + red_loss[4 * tid + 2]) + red_loss[4 * tid + 3];
+  }
 }
 
 // nsplit>1: dOwner = sum_s slab[s] (- r * Y[diag] in user mode); r_out = sum_s r_part[s]   (fixed order)
@@ -323,16 +331,17 @@ __global__ __launch_bounds__(256) void sweep_finish_kernel(SweepArgs a, int d) {
 // MFMA A-operand registers: lane (item, hh) holds users 16*hh .. 16*hh+15 of its item = 64 contiguous bytes);
 // swept = the local users, staged through the same 3-buffer LDS pipeline as the sweep kernel.
 // ------------------------------------------------------------------------------------------
-template <int D>
-__global__ __launch_bounds__(256, 2) void inbatch_gt_kernel(SweepArgs a) {
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void inbatch_gt_kernel(SweepArgs a) {
+  constexpr int NT = NW * 64;
   constexpr int LDY = D + 4;
   constexpr int CT = D / 32;
-  constexpr int NV = (TSW * (D / 4) + 255) / 256;
+  constexpr int NV = (TSW * (D / 4) + NT - 1) / NT;
   __shared__ __attribute__((aligned(16))) float Ysh[3][TSW * LDY];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r31 = lane & 31, hh = lane >> 5;
-  const int64_t o_base = (int64_t)blockIdx.x * OW + w * 32;
+  const int64_t o_base = (int64_t)blockIdx.x * (NW * 32) + w * 32;
 
   f32x16 out[CT];
 #pragma unroll
@@ -348,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void inbatch_gt_kernel(SweepArgs a) {
     const int64_t s_base = tile * TSW;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int idx = tid + i * 256;
+      const int idx = tid + i * NT;
       const int r = idx / (D / 4), c4 = idx % (D / 4);
       const int64_t srow = s_base + r;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -359,13 +368,13 @@ __global__ __launch_bounds__(256, 2) void inbatch_gt_kernel(SweepArgs a) {
   auto store_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int idx = tid + i * 256;
+      const int idx = tid + i * NT;
       const int r = idx / (D / 4), c4 = idx % (D / 4);
       if (idx < TSW * (D / 4)) *reinterpret_cast<f32x4*>(&Ysh[buf][r * LDY + c4 * 4]) = stage[i];
     }
   };
   // this wave's G^T block row; consecutive swept tiles are consecutive 4 KB blocks
-  const f32x4* gp = reinterpret_cast<const f32x4*>(a.gmat + ((size_t)(blockIdx.x * 4 + w) * a.g_ub) * 1024 +
+  const f32x4* gp = reinterpret_cast<const f32x4*>(a.gmat + ((size_t)(blockIdx.x * NW + w) * a.g_ub) * 1024 +
                                                    r31 * 32 + 16 * hh);
   f32x4 gc[4], gn[4], gq[4];  // G of tile, tile+1, tile+2
 #pragma unroll
@@ -383,9 +392,9 @@ __global__ __launch_bounds__(256, 2) void inbatch_gt_kernel(SweepArgs a) {
     }
     __syncthreads();
   }
+  int it = 0;
 #pragma unroll 1
-  for (int64_t tile = t0; tile < t1; ++tile) {
-    const int it = (int)((tile - t0) % 3);
+  for (int64_t tile = t0; tile < t1; ++tile, it = (it == 2 ? 0 : it + 1)) {
     const int cur = it, pre = (it + 2) % 3;
     const bool has_pre = (tile + 2 < t1);
     if (has_pre) {
@@ -409,7 +418,9 @@ __global__ __launch_bounds__(256, 2) void inbatch_gt_kernel(SweepArgs a) {
       gc[q] = gn[q];
       gn[q] = gq[q];
     }
+#ifndef RIHIP_EXPERIMENT_NO_BARRIER
     __syncthreads();
+#endif
   }
 
   const bool final_pass = (a.nsplit == 1);
@@ -453,18 +464,38 @@ __global__ __launch_bounds__(256) void gt_finish_kernel(SweepArgs a, int d) {
 }
 
 template <int D>
-void launch_sweep(bool mode_user, const SweepArgs& a, dim3 grid, hipStream_t st) {
+void launch_sweep(bool mode_user, const SweepArgs& a, dim3 grid, int nw, hipStream_t st) {
+  if (nw == 8) {
+    if (mode_user && a.gmat) hipLaunchKernelGGL((inbatch_sweep_kernel<D, true, true, 8>), grid, dim3(512), 0, st, a);
+    else if (mode_user) hipLaunchKernelGGL((inbatch_sweep_kernel<D, true, false, 8>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((inbatch_sweep_kernel<D, false, false, 8>), grid, dim3(512), 0, st, a);
+    return;
+  }
   if (mode_user && a.gmat) hipLaunchKernelGGL((inbatch_sweep_kernel<D, true, true>), grid, dim3(256), 0, st, a);
   else if (mode_user) hipLaunchKernelGGL((inbatch_sweep_kernel<D, true>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((inbatch_sweep_kernel<D, false>), grid, dim3(256), 0, st, a);
 }
 
-int sweep_nsplit(int64_t n_owner, int64_t n_swept) {
-  const int64_t gx = (n_owner + OW - 1) / OW;
+// workgroup shape: 8 waves x 32 owners (one workgroup per CU) once the problem is large enough to fill the chip that
+// way -- the swept tile is then fetched once per 256 owners instead of once per 128; 4 waves otherwise.
+int sweep_nw(int64_t n_owner, int64_t n_swept) {
+  static const char* ev = getenv("RIHIP_SWEEP_NW");
+  if (ev) return atoi(ev) == 8 ? 8 : 4;
+  return (n_owner >= 4096 && n_swept >= 4096) ? 8 : 4;
+}
+
+// swept-range splits (bounded by the 128-owner formula: the workspace / loss-part sizes are computed from it)
+int sweep_nsplit(int64_t n_owner, int64_t n_swept, int nw = 4) {
   const int64_t tiles = (n_swept + TSW - 1) / TSW;
-  int64_t ns = (2 * RIHIP_NCU + gx - 1) / gx;  // aim at >= 2 workgroups per CU
-  if (ns > 16) ns = 16;
-  if (ns > tiles) ns = tiles;
+  const int64_t gx4 = (n_owner + OW - 1) / OW;
+  int64_t ns4 = (2 * RIHIP_NCU + gx4 - 1) / gx4;  // 4-wave workgroups: aim at >= 2 workgroups per CU
+  if (ns4 > 16) ns4 = 16;
+  if (ns4 > tiles) ns4 = tiles;
+  if (ns4 < 1) ns4 = 1;
+  if (nw == 4) return (int)ns4;
+  const int64_t gx8 = (n_owner + 2 * OW - 1) / (2 * OW);
+  int64_t ns = (RIHIP_NCU + gx8 - 1) / gx8;      // 8-wave workgroups: >= 1 per CU
+  if (ns > ns4) ns = ns4;
   if (ns < 1) ns = 1;
   return (int)ns;
 }
@@ -499,7 +530,7 @@ extern "C" int rihip_rowdot(const float* U, const float* I, int64_t B, int64_t i
 // loss partials written per sweep (doubles) and float workspace (split slabs) needed by rihip_inbatch_sweep
 extern "C" int64_t rihip_inbatch_workspace_doubles(int64_t n_owner) { return ((n_owner + OW - 1) / OW) * 16 + 1; }
 extern "C" int64_t rihip_inbatch_loss_parts(int64_t n_owner, int64_t n_swept) {
-  return ((n_owner + OW - 1) / OW) * sweep_nsplit(n_owner, n_swept);
+  return ((n_owner + OW - 1) / OW) * sweep_nsplit(n_owner, n_swept, sweep_nw(n_owner, n_swept));
 }
 extern "C" int64_t rihip_inbatch_workspace_floats(int64_t n_owner, int64_t n_swept, int d) {
   const int ns = sweep_nsplit(n_owner, n_swept);
@@ -524,16 +555,18 @@ extern "C" int rihip_inbatch_sweep(int mode_user, const float* owners, int64_t n
   a.pos = pos; a.r_in = r_in; a.c = (float)(1.0 / ((double)n_global * (double)(n_global - 1)));
   a.dOwner = d_owner; a.r_out = r_out; a.loss_part = loss_part;
   a.gmat = nullptr; a.g_ub = 0;
-  a.nsplit = sweep_nsplit(n_owner, n_swept);
+  const int nw_f32 = sweep_nw(n_owner, n_swept);
+  const int nw = precision == 1 ? 4 : nw_f32;   // the split-bf16 kernel has 4-wave workgroups only
+  a.nsplit = sweep_nsplit(n_owner, n_swept, nw_f32);
   RIHIP_REQUIRE(a.nsplit == 1 || workspace, RIHIP_ERR_ARG, "inbatch_sweep: workspace required (nsplit=%d)", a.nsplit);
   a.slab = workspace;
   a.r_part = workspace ? workspace + (size_t)a.nsplit * n_owner * d : nullptr;
-  const dim3 grid((unsigned)((n_owner + OW - 1) / OW), (unsigned)a.nsplit);
+  const dim3 grid((unsigned)((n_owner + nw * 32 - 1) / (nw * 32)), (unsigned)a.nsplit);
   hipStream_t st = (hipStream_t)stream;
   if (precision == 1) rihip_launch_sweep_bf16x3(d, mode_user != 0, a, grid, st);
-  else if (d == 32) launch_sweep<32>(mode_user != 0, a, grid, st);
-  else if (d == 64) launch_sweep<64>(mode_user != 0, a, grid, st);
-  else launch_sweep<128>(mode_user != 0, a, grid, st);
+  else if (d == 32) launch_sweep<32>(mode_user != 0, a, grid, nw, st);
+  else if (d == 64) launch_sweep<64>(mode_user != 0, a, grid, nw, st);
+  else launch_sweep<128>(mode_user != 0, a, grid, nw, st);
   RIHIP_CHECK_LAUNCH();
   if (a.nsplit > 1) {
     const int64_t n4 = n_owner * (d / 4);
@@ -546,7 +579,7 @@ extern "C" int rihip_inbatch_sweep(int mode_user, const float* owners, int64_t n
 
 // ---- stored-G variant: user pass writes G, item pass is a plain G^T.U product --------------------------------------
 extern "C" int64_t rihip_inbatch_gmat_floats(int64_t n_users, int64_t n_items) {
-  const int64_t ub = 4 * ((n_users + OW - 1) / OW), ib = 4 * ((n_items + OW - 1) / OW);
+  const int64_t ub = 8 * ((n_users + 2 * OW - 1) / (2 * OW)), ib = 8 * ((n_items + 2 * OW - 1) / (2 * OW));
   return ub * ib * 1024;
 }
 
@@ -564,16 +597,17 @@ extern "C" int rihip_inbatch_user_pass(const float* users, int64_t n_users, int6
   a.Xo = users; a.No = n_users; a.o_goff = user_goff; a.Ys = items; a.Ns = n_items; a.s_goff = item_goff;
   a.pos = pos; a.r_in = nullptr; a.c = (float)(1.0 / ((double)n_global * (double)(n_global - 1)));
   a.dOwner = d_users; a.r_out = r_out; a.loss_part = loss_part;
-  a.gmat = gmat; a.g_ub = 4 * ((n_users + OW - 1) / OW);
-  a.nsplit = sweep_nsplit(n_users, n_items);
+  a.gmat = gmat; a.g_ub = 8 * ((n_users + 2 * OW - 1) / (2 * OW));
+  const int nw = sweep_nw(n_users, n_items);
+  a.nsplit = sweep_nsplit(n_users, n_items, nw);
   RIHIP_REQUIRE(a.nsplit == 1 || workspace, RIHIP_ERR_ARG, "inbatch_user_pass: workspace required (nsplit=%d)", a.nsplit);
   a.slab = workspace;
   a.r_part = workspace ? workspace + (size_t)a.nsplit * n_users * d : nullptr;
-  const dim3 grid((unsigned)((n_users + OW - 1) / OW), (unsigned)a.nsplit);
+  const dim3 grid((unsigned)((n_users + nw * 32 - 1) / (nw * 32)), (unsigned)a.nsplit);
   hipStream_t st = (hipStream_t)stream;
-  if (d == 32) launch_sweep<32>(true, a, grid, st);
-  else if (d == 64) launch_sweep<64>(true, a, grid, st);
-  else launch_sweep<128>(true, a, grid, st);
+  if (d == 32) launch_sweep<32>(true, a, grid, nw, st);
+  else if (d == 64) launch_sweep<64>(true, a, grid, nw, st);
+  else launch_sweep<128>(true, a, grid, nw, st);
   RIHIP_CHECK_LAUNCH();
   if (a.nsplit > 1) {
     const int64_t n4 = n_users * (d / 4);
@@ -593,15 +627,25 @@ extern "C" int rihip_inbatch_item_pass(const float* gmat, const float* users, in
   SweepArgs a;
   a.Xo = nullptr; a.No = n_items; a.o_goff = item_goff; a.Ys = users; a.Ns = n_users; a.s_goff = user_goff;
   a.pos = nullptr; a.r_in = r; a.c = 0.f; a.dOwner = d_items; a.r_out = nullptr; a.loss_part = nullptr;
-  a.gmat = const_cast<float*>(gmat); a.g_ub = 4 * ((n_users + OW - 1) / OW);
-  a.nsplit = sweep_nsplit(n_items, n_users);
+  a.gmat = const_cast<float*>(gmat); a.g_ub = 8 * ((n_users + 2 * OW - 1) / (2 * OW));
+  // 8-wave workgroups (256 items) halve the L2->L1 traffic of the swept user tiles; used when they still fill the chip
+  const int nw = sweep_nw(n_items, n_users);
+  const int ow = nw * 32;
+  const int64_t gx = (n_items + ow - 1) / ow;
+  a.nsplit = sweep_nsplit(n_items, n_users, nw);
   RIHIP_REQUIRE(a.nsplit == 1 || workspace, RIHIP_ERR_ARG, "inbatch_item_pass: workspace required (nsplit=%d)", a.nsplit);
   a.slab = workspace; a.r_part = nullptr;
-  const dim3 grid((unsigned)((n_items + OW - 1) / OW), (unsigned)a.nsplit);
   hipStream_t st = (hipStream_t)stream;
-  if (d == 32) hipLaunchKernelGGL((inbatch_gt_kernel<32>), grid, dim3(256), 0, st, a);
-  else if (d == 64) hipLaunchKernelGGL((inbatch_gt_kernel<64>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((inbatch_gt_kernel<128>), grid, dim3(256), 0, st, a);
+  const dim3 grid((unsigned)gx, (unsigned)a.nsplit);
+  if (nw == 8) {
+    if (d == 32) hipLaunchKernelGGL((inbatch_gt_kernel<32, 8>), grid, dim3(512), 0, st, a);
+    else if (d == 64) hipLaunchKernelGGL((inbatch_gt_kernel<64, 8>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((inbatch_gt_kernel<128, 8>), grid, dim3(512), 0, st, a);
+  } else {
+    if (d == 32) hipLaunchKernelGGL((inbatch_gt_kernel<32, 4>), grid, dim3(256), 0, st, a);
+    else if (d == 64) hipLaunchKernelGGL((inbatch_gt_kernel<64, 4>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((inbatch_gt_kernel<128, 4>), grid, dim3(256), 0, st, a);
+  }
   RIHIP_CHECK_LAUNCH();
   if (a.nsplit > 1) {
     const int64_t n4 = n_items * (d / 4);

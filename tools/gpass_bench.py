@@ -1,6 +1,6 @@
 """Stored-G in-batch pass vs the two-sweep form: equality + timing.  python tools/gpass_bench.py [B] [d]"""
-import sys, torch
-sys.path.insert(0, ".")
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from recommendit_amd import _lib as L
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
