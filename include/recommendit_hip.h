@@ -106,7 +106,7 @@ int rihip_inbatch_sweep(int mode_user, const float* owners, int64_t n_owner, int
 int rihip_sum_partials(const double* part, int64_t n, double scale, float* out, void* stream);
 
 /* Stored-G form of the same loss (two_tower.py:132-160), the default when memory allows: the user pass is the
- * mode_user=1 sweep that ALSO writes G (sigma(s_ij - s_ii)/(B(B-1)), 0 on the diagonal) to `gmat`
+ * mode_user=1 sweep that ALSO writes the weights sigma(s_ij - s_ii) (0 on the diagonal; G = weight/(B(B-1))) to `gmat`
  * (rihip_inbatch_gmat_floats(n_users, n_items) floats, 32x32-blocked G^T); the item pass is then a plain exact-f32
  * product d_items[j] = sum_i G[i][j] users[i] - r_j users[j] over the LOCAL users for ALL n_items items -- no second
  * score sweep (6 B^2 d FLOP per step instead of 8 B^2 d).  Multi-GPU: every rank calls both with its local users and
@@ -118,8 +118,8 @@ int rihip_inbatch_user_pass(const float* users, int64_t n_users, int64_t user_go
                             float* d_users, float* r_out, double* loss_part, float* workspace, float* gmat,
                             void* stream);
 int rihip_inbatch_item_pass(const float* gmat, const float* users, int64_t n_users, int64_t user_goff,
-                            int64_t n_items, int64_t item_goff, int d, const float* r, float* d_items,
-                            float* workspace, void* stream);
+                            int64_t n_items, int64_t item_goff, int d, const float* r, int64_t n_global,
+                            float* d_items, float* workspace, void* stream);
 
 /* ---- optimiser -----------------------------------------------------------------------------
  * clip_grad_norm_(max_norm) (train_embeddings.py:191): rihip_sumsq writes rihip_sumsq_nparts()

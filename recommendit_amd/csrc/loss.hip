@@ -108,9 +108,13 @@ __global__ __launch_bounds__(NW * 64, 2) void inbatch_sweep_kernel(SweepArgs a) 
   {
     const int64_t orow = o_ok ? o_loc : (a.No - 1);
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) xo[kb] = *reinterpret_cast<const f32x4*>(&a.Xo[orow * D + kb * 8 + 4 * hh]);
+    for (int kb = 0; kb < KB; ++kb) {
+      xo[kb] = *reinterpret_cast<const f32x4*>(&a.Xo[orow * D + kb * 8 + 4 * hh]);
+      xo[kb] *= RIHIP_LOG2E;  // scores come out of the MFMA chain in log2 units (sweep_elem)
+    }
   }
-  const float pos_o = (MODE_USER && o_ok) ? a.pos[o_loc] : 0.f;
+  const float pos_o = (MODE_USER && o_ok) ? a.pos[o_loc] * RIHIP_LOG2E : 0.f;
+  const float inv_c = 1.f / a.c;
 
   f32x16 out[CT];
 #pragma unroll
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(NW * 64, 2) void inbatch_sweep_kernel(SweepArgs a) 
     }
     if (!MODE_USER && tid < TSW) {
       const int64_t srow = s_base + tid;
-      st_pos = (srow < a.Ns) ? a.pos[srow] : 0.f;
+      st_pos = (srow < a.Ns) ? a.pos[srow] * RIHIP_LOG2E : 0.f;
       st_r = (srow < a.Ns) ? a.r_in[srow] : 0.f;
     }
   };
@@ -199,10 +203,12 @@ __global__ __launch_bounds__(NW * 64, 2) void inbatch_sweep_kernel(SweepArgs a) 
     const float* Yc = Ysh[cur];
     f32x16 sn = zero16();
     float g[16];
+    float den_prod = 1.f;  // running product of (1 + e^-z): one log per eight elements
     if (!slow) {
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
-        if (has_next) {
+        {  // unconditional: on the last tile this multiplies a stale buffer and the result is dropped -- a branch
+           // here splits the block and the scheduler then parks all the VALU work behind the MFMA chain
           const f32x4 av = *reinterpret_cast<const f32x4*>(&Yn[r31 * LDY + kb * 8 + 4 * hh]);
           sn = mfma32(av.x, xo[kb].x, sn);
           sn = mfma32(av.y, xo[kb].y, sn);
@@ -213,13 +219,18 @@ __global__ __launch_bounds__(NW * 64, 2) void inbatch_sweep_kernel(SweepArgs a) 
         for (int e = 0; e < EPK; ++e) {
           const int r = kb * EPK + e;
           const float pos = MODE_USER ? pos_o : posS[cur][acc_row(r, lane)];
-          g[r] = sweep_elem<MODE_USER, true>(st[r], pos, a.c, true, false, 0.f, loss_acc, r_acc);
+          g[r] = sweep_elem<MODE_USER, true>(st[r], pos, true, false, 0.f, loss_acc, den_prod, r_acc);
+          if (MODE_USER && (r & 7) == 7) {
+            loss_acc += __builtin_amdgcn_logf(den_prod);
+            den_prod = 1.f;
+          }
         }
       }
     } else {
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
-        if (has_next) {
+        {  // unconditional: on the last tile this multiplies a stale buffer and the result is dropped -- a branch
+           // here splits the block and the scheduler then parks all the VALU work behind the MFMA chain
           const f32x4 av = *reinterpret_cast<const f32x4*>(&Yn[r31 * LDY + kb * 8 + 4 * hh]);
           sn = mfma32(av.x, xo[kb].x, sn);
           sn = mfma32(av.y, xo[kb].y, sn);
@@ -233,8 +244,12 @@ __global__ __launch_bounds__(NW * 64, 2) void inbatch_sweep_kernel(SweepArgs a) 
           const bool valid = o_ok && (sl < n_valid);
           const bool diag = (sl - r31 == ddi);
           const float pos = MODE_USER ? pos_o : posS[cur][sl];
-          const float rd = MODE_USER ? 0.f : -rS[cur][sl];
-          g[r] = sweep_elem<MODE_USER, false>(st[r], pos, a.c, valid, diag, rd, loss_acc, r_acc);
+          const float rd = MODE_USER ? 0.f : -rS[cur][sl] * inv_c;  // weights are unscaled until the epilogue
+          g[r] = sweep_elem<MODE_USER, false>(st[r], pos, valid, diag, rd, loss_acc, den_prod, r_acc);
+          if (MODE_USER && (r & 7) == 7) {
+            loss_acc += __builtin_amdgcn_logf(den_prod);
+            den_prod = 1.f;
+          }
         }
       }
     }
@@ -258,11 +273,11 @@ __global__ __launch_bounds__(NW * 64, 2) void inbatch_sweep_kernel(SweepArgs a) 
 
   // ---- epilogue
   if (t0 < t1) {
-    const float rr = r_acc + __shfl_xor(r_acc, 32, 64);  // both halves hold the same owner column
+    const float rr = (r_acc + __shfl_xor(r_acc, 32, 64)) * a.c;  // both halves hold the same owner column
     if (hh == 0) rsum[w][r31] = rr;
     if (MODE_USER) {
       const float ls = wave_sum(loss_acc);
-      if (lane == 0) red_loss[w] = (double)ls;
+      if (lane == 0) red_loss[w] = (double)ls * (double)RIHIP_LN2;  // log2 units -> nats
     }
   }
   __syncthreads();
@@ -278,7 +293,7 @@ __global__ __launch_bounds__(NW * 64, 2) void inbatch_sweep_kernel(SweepArgs a) 
       const float rs = rsum[w][o];
 #pragma unroll
       for (int t = 0; t < CT; ++t) {
-        float v = out[t][r];
+        float v = out[t][r] * a.c;
         if (fix) v -= rs * a.Ys[drow * D + t * 32 + r31];  // G_ii = -sum_{j!=i} G_ij
         dst[orow * D + t * 32 + r31] = v;
       }
@@ -434,7 +449,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void inbatch_gt_kernel(Sw
       const float rs = fix ? a.r_in[drow] : 0.f;
 #pragma unroll
       for (int t = 0; t < CT; ++t) {
-        float v = out[t][r];
+        float v = out[t][r] * a.c;                          // the stored weights are unscaled sigma(z)
         if (fix) v -= rs * a.Ys[drow * D + t * 32 + r31];  // G_jj = -r_j
         dst[orow * D + t * 32 + r31] = v;
       }
@@ -618,15 +633,16 @@ extern "C" int rihip_inbatch_user_pass(const float* users, int64_t n_users, int6
 }
 
 extern "C" int rihip_inbatch_item_pass(const float* gmat, const float* users, int64_t n_users, int64_t user_goff,
-                                       int64_t n_items, int64_t item_goff, int d, const float* r, float* d_items,
-                                       float* workspace, void* stream) {
+                                       int64_t n_items, int64_t item_goff, int d, const float* r, int64_t n_global,
+                                       float* d_items, float* workspace, void* stream) {
   RIHIP_REQUIRE(d == 32 || d == 64 || d == 128, RIHIP_ERR_SHAPE, "inbatch_item_pass: unsupported embed_dim=%d", d);
   RIHIP_REQUIRE(gmat && users && r && d_items, RIHIP_ERR_ARG, "inbatch_item_pass: null pointer");
-  RIHIP_REQUIRE(n_users > 0 && n_items > 0, RIHIP_ERR_ARG, "inbatch_item_pass: sizes users=%lld items=%lld",
-                (long long)n_users, (long long)n_items);
+  RIHIP_REQUIRE(n_users > 0 && n_items > 0 && n_global >= 2, RIHIP_ERR_ARG,
+                "inbatch_item_pass: sizes users=%lld items=%lld B=%lld", (long long)n_users, (long long)n_items,
+                (long long)n_global);
   SweepArgs a;
   a.Xo = nullptr; a.No = n_items; a.o_goff = item_goff; a.Ys = users; a.Ns = n_users; a.s_goff = user_goff;
-  a.pos = nullptr; a.r_in = r; a.c = 0.f; a.dOwner = d_items; a.r_out = nullptr; a.loss_part = nullptr;
+  a.pos = nullptr; a.r_in = r; a.c = (float)(1.0 / ((double)n_global * (double)(n_global - 1))); a.dOwner = d_items; a.r_out = nullptr; a.loss_part = nullptr;
   a.gmat = const_cast<float*>(gmat); a.g_ub = 8 * ((n_users + 2 * OW - 1) / (2 * OW));
   // 8-wave workgroups (256 items) halve the L2->L1 traffic of the swept user tiles; used when they still fill the chip
   const int nw = sweep_nw(n_items, n_users);

@@ -54,8 +54,9 @@ __global__ __launch_bounds__(256, 2) void inbatch_sweep_bf16_kernel(SweepArgs a)
     const int64_t orow = o_ok ? o_loc : (a.No - 1);
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(&a.Xo[orow * D + kb * 16 + 8 * hh]);
-      const f32x4 v1 = *reinterpret_cast<const f32x4*>(&a.Xo[orow * D + kb * 16 + 8 * hh + 4]);
+      // pre-scaled by log2(e): scores leave the MFMA chain in log2 units (sweep_elem)
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(&a.Xo[orow * D + kb * 16 + 8 * hh]) * RIHIP_LOG2E;
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(&a.Xo[orow * D + kb * 16 + 8 * hh + 4]) * RIHIP_LOG2E;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         __bf16 h0, l0, h1, l1;
@@ -65,7 +66,8 @@ __global__ __launch_bounds__(256, 2) void inbatch_sweep_bf16_kernel(SweepArgs a)
       }
     }
   }
-  const float pos_o = (MODE_USER && o_ok) ? a.pos[o_loc] : 0.f;
+  const float pos_o = (MODE_USER && o_ok) ? a.pos[o_loc] * RIHIP_LOG2E : 0.f;
+  const float inv_c = 1.f / a.c;
 
   f32x16 out[CT];
 #pragma unroll
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void inbatch_sweep_bf16_kernel(SweepArgs a)
     }
     if (!MODE_USER && tid < TSW) {
       const int64_t srow = s_base + tid;
-      st_pos = (srow < a.Ns) ? a.pos[srow] : 0.f;
+      st_pos = (srow < a.Ns) ? a.pos[srow] * RIHIP_LOG2E : 0.f;
       st_r = (srow < a.Ns) ? a.r_in[srow] : 0.f;
     }
   };
@@ -164,11 +166,16 @@ __global__ __launch_bounds__(256, 2) void inbatch_sweep_bf16_kernel(SweepArgs a)
     const int64_t left = a.Ns - s_base;
     const int n_valid = left < TSW ? (int)left : TSW;
     float g[16];
+    float den_prod = 1.f;
     if (!slow) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float pos = MODE_USER ? pos_o : posS[cur][acc_row(r, lane)];
-        g[r] = sweep_elem<MODE_USER, true>(st[r], pos, a.c, true, false, 0.f, loss_acc, r_acc);
+        g[r] = sweep_elem<MODE_USER, true>(st[r], pos, true, false, 0.f, loss_acc, den_prod, r_acc);
+        if (MODE_USER && (r & 7) == 7) {
+          loss_acc += __builtin_amdgcn_logf(den_prod);
+          den_prod = 1.f;
+        }
       }
     } else {
 #pragma unroll
@@ -177,8 +184,12 @@ __global__ __launch_bounds__(256, 2) void inbatch_sweep_bf16_kernel(SweepArgs a)
         const bool valid = o_ok && (sl < n_valid);
         const bool diag = (sl - r31 == ddi);
         const float pos = MODE_USER ? pos_o : posS[cur][sl];
-        const float rd = MODE_USER ? 0.f : -rS[cur][sl];
-        g[r] = sweep_elem<MODE_USER, false>(st[r], pos, a.c, valid, diag, rd, loss_acc, r_acc);
+        const float rd = MODE_USER ? 0.f : -rS[cur][sl] * inv_c;
+        g[r] = sweep_elem<MODE_USER, false>(st[r], pos, valid, diag, rd, loss_acc, den_prod, r_acc);
+        if (MODE_USER && (r & 7) == 7) {
+          loss_acc += __builtin_amdgcn_logf(den_prod);
+          den_prod = 1.f;
+        }
       }
     }
     // ---- dOwner[o][c] += sum_s G[s][o] Y[s][c]: registers 8s..8s+7 are the A fragment of k-step s
@@ -213,11 +224,11 @@ __global__ __launch_bounds__(256, 2) void inbatch_sweep_bf16_kernel(SweepArgs a)
 
   // ---- epilogue (identical to the f32 kernel)
   if (t0 < t1) {
-    const float rr = r_acc + __shfl_xor(r_acc, 32, 64);
+    const float rr = (r_acc + __shfl_xor(r_acc, 32, 64)) * a.c;
     if (hh == 0) rsum[w][r31] = rr;
     if (MODE_USER) {
       const float ls = wave_sum(loss_acc);
-      if (lane == 0) red_loss[w] = (double)ls;
+      if (lane == 0) red_loss[w] = (double)ls * (double)RIHIP_LN2;
     }
   }
   __syncthreads();
@@ -233,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void inbatch_sweep_bf16_kernel(SweepArgs a)
       const float rs = rsum[w][o];
 #pragma unroll
       for (int t = 0; t < CT; ++t) {
-        float v = out[t][r];
+        float v = out[t][r] * a.c;
         if (fix) v -= rs * a.Ys[drow * D + t * 32 + r31];
         dst[orow * D + t * 32 + r31] = v;
       }

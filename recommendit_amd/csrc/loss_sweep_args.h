@@ -35,21 +35,27 @@ constexpr int TSW = 32;  // swept rows per LDS tile (shared by the 4 waves)
 // Tiles that contain neither the diagonal nor a ragged edge take a branch-free element path.
 // gridDim.y splits the swept range so that small batches still fill the chip; partial owner gradients of the
 // splits are combined in fixed order by sweep_finish_kernel.
+// One score element.  Inputs are in log2 units (owners and pos are pre-scaled by log2(e)), so
+//   z2 = log2(e) (s_ij - s_ii),  e = 2^-z2 = e^-z,  sigma(z) = 1/(1+e),  softplus(z) = z + log(1+e).
+// VALU instructions are NOT hidden beside v_mfma_f32_32x32x2_f32 (measured: ~2.8 cycles per simple op, ~7.3 per
+// transcendental, on top of the MFMA's 64), so the element is kept at 7 instructions: sub, exp, add, rcp and three
+// accumulates; the scale c = 1/(B(B-1)) is applied once in the epilogue, the logs are taken on products of eight
+// factors (1+e <= 1+e^|z|: eight of them overflow f32 only for mean |z| > 11; L2-normalised rows have |z| <= 2).
+// e = +inf (z << 0) gives sigma = 0, e = 0 gives sigma = 1: the right limits without a branch.
+// Returns the UNSCALED gradient weight sigma(z) (0 for masked elements; r_diag on the diagonal in item mode).
+constexpr float RIHIP_LOG2E = 1.4426950408889634f;
+constexpr float RIHIP_LN2 = 0.6931471805599453f;
 template <bool MODE_USER, bool FAST>
-__device__ __forceinline__ float sweep_elem(float s, float pos, float c, bool valid, bool diag, float r_diag,
-                                            float& loss_acc, float& r_acc) {
-  const float z = s - pos;
-  const float e = __expf(-fabsf(z));
+__device__ __forceinline__ float sweep_elem(float s2, float pos2, bool valid, bool diag, float r_diag,
+                                            float& loss2_acc, float& den_prod, float& r_acc) {
+  const float z2 = s2 - pos2;
+  const float e = __builtin_amdgcn_exp2f(-z2);
   const float den = 1.f + e;
-  const float sig = ((z >= 0.f) ? 1.f : e) * __builtin_amdgcn_rcpf(den);
-  float gv = sig * c;
+  float gv = __builtin_amdgcn_rcpf(den);
   if (MODE_USER) {
-    const float sp = fmaxf(z, 0.f) + __logf(den);
-    if (FAST) {
-      loss_acc += sp;
-      r_acc += gv;
-    } else if (valid && !diag) {
-      loss_acc += sp;
+    if (FAST || (valid && !diag)) {
+      loss2_acc += z2;
+      den_prod *= den;
       r_acc += gv;
     } else {
       gv = 0.f;
@@ -60,4 +66,3 @@ __device__ __forceinline__ float sweep_elem(float s, float pos, float c, bool va
   }
   return gv;
 }
-

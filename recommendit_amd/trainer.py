@@ -357,7 +357,7 @@ class HipBPRTrainer:
                         self.sws.data_ptr(), self.gmat.data_ptr(), st)
             dI_all = self.dI if W == 1 else self.dI_all
             self._timed(lib.rihip_inbatch_item_pass, "inbatch_item_pass", self.gmat.data_ptr(), self.U.data_ptr(), B,
-                        off, G, 0, d, self.r.data_ptr(), dI_all.data_ptr(), self.sws.data_ptr(), st)
+                        off, G, 0, d, self.r.data_ptr(), G, dI_all.data_ptr(), self.sws.data_ptr(), st)
             if W > 1:
                 self._dI_work = reduce_scatter_sum(self.dI, self.dI_all, self.pg, async_op=True)
         elif W == 1:

@@ -209,7 +209,7 @@ def inbatch_loss_and_grads(U: torch.Tensor, I: torch.Tensor, precision: int = 0,
         L.check(lib.rihip_inbatch_user_pass(Uc.data_ptr(), B, 0, Ic.data_ptr(), B, 0, d, posv.data_ptr(), B,
                                             dU.data_ptr(), rv.data_ptr(), part.data_ptr(), ws.data_ptr(),
                                             gm.data_ptr(), st), "inbatch_user_pass")
-        L.check(lib.rihip_inbatch_item_pass(gm.data_ptr(), Uc.data_ptr(), B, 0, B, 0, d, rv.data_ptr(), dI.data_ptr(),
+        L.check(lib.rihip_inbatch_item_pass(gm.data_ptr(), Uc.data_ptr(), B, 0, B, 0, d, rv.data_ptr(), B, dI.data_ptr(),
                                             ws.data_ptr(), st), "inbatch_item_pass")
         L.check(lib.rihip_sum_partials(part.data_ptr(), lib.rihip_inbatch_loss_parts(B, B), 1.0 / (B * (B - 1.0)),
                                        loss.data_ptr(), st), "sum_partials")

@@ -212,7 +212,7 @@ def test_inbatch_stored_g_rectangular_rank_form(Bl, G, off, d):
     L.check(lib.rihip_rowdot(Ud.data_ptr(), Id.data_ptr(), Bl, off, d, pos.data_ptr(), st), "rowdot")
     L.check(lib.rihip_inbatch_user_pass(Ud.data_ptr(), Bl, off, Id.data_ptr(), G, 0, d, pos.data_ptr(), G,
                                         dU.data_ptr(), r.data_ptr(), lp.data_ptr(), ws.data_ptr(), gm.data_ptr(), st), "up")
-    L.check(lib.rihip_inbatch_item_pass(gm.data_ptr(), Ud.data_ptr(), Bl, off, G, 0, d, r.data_ptr(), dI.data_ptr(),
+    L.check(lib.rihip_inbatch_item_pass(gm.data_ptr(), Ud.data_ptr(), Bl, off, G, 0, d, r.data_ptr(), G, dI.data_ptr(),
                                         ws.data_ptr(), st), "ip")
     L.check(lib.rihip_sum_partials(lp.data_ptr(), lib.rihip_inbatch_loss_parts(Bl, G), 1.0 / (G * (G - 1.0)),
                                    loss.data_ptr(), st), "sum")

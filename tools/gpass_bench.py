@@ -26,7 +26,7 @@ def upass():
     L.check(lib.rihip_inbatch_user_pass(U.data_ptr(), B, 0, I.data_ptr(), B, 0, d, pos.data_ptr(), B, dU2.data_ptr(),
                                         r2.data_ptr(), lp.data_ptr(), ws.data_ptr(), gm.data_ptr(), st), "up")
 def ipass():
-    L.check(lib.rihip_inbatch_item_pass(gm.data_ptr(), U.data_ptr(), B, 0, B, 0, d, r2.data_ptr(), dI2.data_ptr(),
+    L.check(lib.rihip_inbatch_item_pass(gm.data_ptr(), U.data_ptr(), B, 0, B, 0, d, r2.data_ptr(), B, dI2.data_ptr(),
                                         ws.data_ptr(), st), "ip")
 two_sweep(); upass(); ipass(); torch.cuda.synchronize()
 print("dU equal", torch.equal(dU, dU2), "r equal", torch.equal(r, r2),
