@@ -391,6 +391,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void inbatch_gt_kernel(Sw
   // this wave's G^T block row; consecutive swept tiles are consecutive 4 KB blocks
   const f32x4* gp = reinterpret_cast<const f32x4*>(a.gmat + ((size_t)(blockIdx.x * NW + w) * a.g_ub) * 1024 +
                                                    r31 * 32 + 16 * hh);
+  // Pipeline: the user tile t+2 and the G block t+2 are requested at the top of iteration t; the tile sits in
+  // registers for one whole iteration and goes to LDS at the top of iteration t+1 (published by that iteration's
+  // barrier, read in iteration t+2).  vmcnt retires in order, so the wait for a tile only covers requests that are
+  // at least one full iteration (64 MFMAs per wave) old -- the HBM stream of G never stalls the L2-resident tile.
   f32x4 gc[4], gn[4], gq[4];  // G of tile, tile+1, tile+2
 #pragma unroll
   for (int q = 0; q < 4; ++q) gc[q] = gn[q] = gq[q] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -402,17 +406,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void inbatch_gt_kernel(Sw
     if (t0 + 1 < t1) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) gn[q] = gp[(size_t)(t0 + 1) * 256 + q];
-      load_tile(t0 + 1);
-      store_tile(1);
+      load_tile(t0 + 1);  // stays in registers until the top of the first iteration
     }
     __syncthreads();
   }
   int it = 0;
 #pragma unroll 1
   for (int64_t tile = t0; tile < t1; ++tile, it = (it == 2 ? 0 : it + 1)) {
-    const int cur = it, pre = (it + 2) % 3;
-    const bool has_pre = (tile + 2 < t1);
-    if (has_pre) {
+    const int cur = it, nxt = (it + 1) % 3;
+    if (tile + 1 < t1) store_tile(nxt);  // buffer nxt was last read two iterations ago
+    if (tile + 2 < t1) {
       load_tile(tile + 2);
 #pragma unroll
       for (int q = 0; q < 4; ++q) gq[q] = gp[(size_t)(tile + 2) * 256 + q];
@@ -427,15 +430,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void inbatch_gt_kernel(Sw
         for (int t = 0; t < CT; ++t) out[t] = mfma32(gc[q][s], Yc[krow * LDY + t * 32 + r31], out[t]);
       }
     }
-    if (has_pre) store_tile(pre);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       gc[q] = gn[q];
       gn[q] = gq[q];
     }
-#ifndef RIHIP_EXPERIMENT_NO_BARRIER
     __syncthreads();
-#endif
   }
 
   const bool final_pass = (a.nsplit == 1);
