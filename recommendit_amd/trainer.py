@@ -267,8 +267,12 @@ class HipBPRTrainer:
         t, lr = 0, 0.0   # the device clock (hyper_dev) overrides the host-side step / lr arguments below
         ukeys, ikeys = _MLP_KEYS[:4], _MLP_KEYS[4:]
         s0 = (self.seed * 1000003 + self.rank * 7919) & ((1 << 62) - 1)   # + device step counter inside the kernel
-        self._fwd(self.utab, user_ids, None, ukeys, self.U, self.hidU, self.denU, s0)
+        # item tower first: in the multi-GPU in-batch mode its outputs travel (all-gather) under the user tower
         self._fwd(self.itab, item_ids, item_genres, ikeys, self.I, self.hidI, self.denI, s0 + 1)
+        self._I_work = None
+        if self.world > 1 and self.loss_mode == "inbatch":
+            self._I_work = all_gather_into(self.I_all, self.I, self.pg, async_op=True)
+        self._fwd(self.utab, user_ids, None, ukeys, self.U, self.hidU, self.denU, s0)
 
         if self.loss_mode == "sampled":
             L.check(lib.rihip_bpr_pair_loss(self.U.data_ptr(), self.I.data_ptr(), self.I[B:].data_ptr(), B, d,
@@ -346,8 +350,9 @@ class HipBPRTrainer:
         L.check(lib.rihip_rowdot(self.U.data_ptr(), self.I.data_ptr(), B, 0, d, self.pos.data_ptr(), st), "rowdot")
         I_all = self.I
         if W > 1:
-            # global in-batch negatives: every rank scores its users against ALL items (4 MiB/rank at B=8192, d=128)
-            all_gather_into(self.I_all, self.I, self.pg)
+            # global in-batch negatives: every rank scores its users against ALL items (4 MiB/rank at B=8192, d=128);
+            # the all-gather was started right after the item tower's forward
+            self._I_work.wait()
             I_all = self.I_all
         if self.inbatch_store_g and self.inbatch_precision == 0:
             # user pass keeps G in HBM; item pass = G^T.U over the local users for all items, reduce-scattered to

@@ -193,7 +193,8 @@ def test_inbatch_stored_g_equals_recompute_form(B, d):
     np.testing.assert_allclose(dI1.cpu().numpy(), dIo, atol=3e-9, rtol=3e-4)
 
 
-@pytest.mark.parametrize("Bl,G,off,d", [(100, 300, 100, 64), (64, 256, 192, 128), (37, 111, 0, 32)])
+@pytest.mark.parametrize("Bl,G,off,d", [(100, 300, 100, 64), (64, 256, 192, 128), (37, 111, 0, 32),
+                                         (4100, 4230, 77, 64)])   # last: 8-wave workgroups, ragged, split sweeps
 def test_inbatch_stored_g_rectangular_rank_form(Bl, G, off, d):
     """Multi-GPU shape of the stored-G passes through the C ABI: local users [Bl] (positives = items off..off+Bl)
     against all G items; the item pass returns this rank's partial dI for ALL items (oracle: rectangular form)."""
@@ -220,6 +221,23 @@ def test_inbatch_stored_g_rectangular_rank_form(Bl, G, off, d):
     assert abs(loss.item() - float(lo)) < 3e-6
     np.testing.assert_allclose(dU.cpu().numpy(), dUo, atol=3e-9, rtol=3e-4)
     np.testing.assert_allclose(dI.cpu().numpy(), dIo, atol=3e-9, rtol=3e-4)
+
+
+def test_inbatch_unnormalised_inputs_keep_the_limits():
+    """The element works in the log2 domain with sigma = 1/(1+2^-z2) and one log per 8 factors of (1+e^-z): rows of
+    norm 2 (|z| up to 8) must still match the oracle, and saturated scores (|z| ~ 200) must give finite gradients
+    (sigma -> 0 / 1) -- the loss may overflow there, by design."""
+    from recommendit_amd.two_tower import inbatch_loss_and_grads
+    rng = np.random.RandomState(5)
+    B, d = 96, 32
+    U, I = 2.0 * fx.unit_rows(rng, B, d), 2.0 * fx.unit_rows(rng, B, d)
+    loss, dU, dI = inbatch_loss_and_grads(t(U), t(I))
+    lo, dUo, dIo = O.in_batch_bpr_loss(U, I)
+    assert abs(loss.item() - float(lo)) < 2e-5 * max(1.0, float(lo))
+    np.testing.assert_allclose(dU.cpu().numpy(), dUo, atol=2e-8, rtol=1e-3)
+    np.testing.assert_allclose(dI.cpu().numpy(), dIo, atol=2e-8, rtol=1e-3)
+    _, dU2, dI2 = inbatch_loss_and_grads(t(10.0 * U), t(10.0 * I))
+    assert torch.isfinite(dU2).all() and torch.isfinite(dI2).all()
 
 
 def test_inbatch_full_size_properties():
