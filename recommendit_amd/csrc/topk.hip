@@ -660,6 +660,61 @@ __global__ __launch_bounds__(256) void ivf_assign_kernel(const float* __restrict
   }
 }
 
+// MFMA form of the assignment (d in {32,64,128}): 4 waves x 32 register-stationary rows per workgroup, centroid tiles
+// of 32 through LDS, S[centroid][row] on exact-f32 MFMA, arg-max over the accumulator rows (lowest index wins ties).
+template <int D>
+__global__ __launch_bounds__(256, 2) void ivf_assign_mfma_kernel(const float* __restrict__ X, int64_t N,
+                                                                 const float* __restrict__ C, int nlist, int* assign) {
+  constexpr int LDC = D + 4, KB = D / 8;
+  constexpr int NV = (32 * (D / 4) + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float Cs[32 * LDC];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r31 = lane & 31, hh = lane >> 5;
+  const int ntile = (nlist + 31) / 32;
+  for (int64_t blk = blockIdx.x; blk * 128 < N; blk += gridDim.x) {
+    const int64_t row = blk * 128 + w * 32 + r31;
+    const int64_t rowc = row < N ? row : N - 1;
+    f32x4 xr[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) xr[kb] = *reinterpret_cast<const f32x4*>(&X[rowc * D + kb * 8 + 4 * hh]);
+    float best = -INFINITY;
+    int bi = 0;
+    for (int t = 0; t < ntile; ++t) {
+      __syncthreads();  // previous tile fully consumed
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int idx = tid + i * 256;
+        const int r = idx / (D / 4), c4 = idx % (D / 4);
+        if (idx < 32 * (D / 4)) {
+          const int c = t * 32 + r;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (c < nlist) v = reinterpret_cast<const f32x4*>(C + (size_t)c * D)[c4];
+          *reinterpret_cast<f32x4*>(&Cs[r * LDC + c4 * 4]) = v;
+        }
+      }
+      __syncthreads();
+      f32x16 acc = zero16();
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(&Cs[r31 * LDC + kb * 8 + 4 * hh]);
+        acc = mfma32(av.x, xr[kb].x, acc);
+        acc = mfma32(av.y, xr[kb].y, acc);
+        acc = mfma32(av.z, xr[kb].z, acc);
+        acc = mfma32(av.w, xr[kb].w, acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {  // acc_row(r, lane) grows with r: '>' keeps the lowest centroid on ties
+        const int c = t * 32 + acc_row(r, lane);
+        if (c < nlist && acc[r] > best) { best = acc[r]; bi = c; }
+      }
+    }
+    const float ob = __shfl_xor(best, 32, 64);
+    const int oi = __shfl_xor(bi, 32, 64);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    if (hh == 0 && row < N) assign[row] = bi;
+  }
+}
+
 // per-workgroup LDS accumulation of centroid sums, then one slab per workgroup (deterministic reduce)
 __global__ __launch_bounds__(256) void ivf_accum_kernel(const float* __restrict__ X, int64_t N, int d,
                                                         const int* __restrict__ assign, int nlist, float* slab,
@@ -1148,7 +1203,7 @@ extern "C" int rihip_ip_index_train_ivf(void* handle, int nlist, int n_iter, uin
   for (int c = 0; c < nlist; ++c)
     HIPCHK(hipMemcpyAsync(h->C + (size_t)c * d, h->X + (size_t)pick[c] * d, sizeof(float) * d, hipMemcpyDeviceToDevice, st));
   int* assign = nullptr; float* slab = nullptr; int* cnt_slab = nullptr; int* counts = nullptr;
-  const int NSL = 256;
+  const int NSL = 768;  // 3 workgroups per CU (LDS-bound), one deterministic slab each
   HIPCHK(hipMalloc((void**)&assign, sizeof(int) * N));
   HIPCHK(hipMalloc((void**)&slab, sizeof(float) * (size_t)NSL * nlist * d));
   HIPCHK(hipMalloc((void**)&cnt_slab, sizeof(int) * (size_t)NSL * nlist));
@@ -1156,7 +1211,14 @@ extern "C" int rihip_ip_index_train_ivf(void* handle, int nlist, int n_iter, uin
   const size_t lds_c = sizeof(float) * nlist * d;
   const int agrid = (int)((N + 3) / 4 < 2048 ? (N + 3) / 4 : 2048);
   for (int it = 0; it <= n_iter; ++it) {
-    hipLaunchKernelGGL(ivf_assign_kernel, dim3(agrid), dim3(256), lds_c, st, h->X, N, d, h->C, nlist, assign);
+    {
+      const int64_t nblk = (N + 127) / 128;
+      const dim3 mg((unsigned)(nblk < 2048 ? nblk : 2048));
+      if (d == 128) hipLaunchKernelGGL((ivf_assign_mfma_kernel<128>), mg, dim3(256), 0, st, h->X, N, h->C, nlist, assign);
+      else if (d == 64) hipLaunchKernelGGL((ivf_assign_mfma_kernel<64>), mg, dim3(256), 0, st, h->X, N, h->C, nlist, assign);
+      else if (d == 32) hipLaunchKernelGGL((ivf_assign_mfma_kernel<32>), mg, dim3(256), 0, st, h->X, N, h->C, nlist, assign);
+      else hipLaunchKernelGGL(ivf_assign_kernel, dim3(agrid), dim3(256), lds_c, st, h->X, N, d, h->C, nlist, assign);
+    }
     hipLaunchKernelGGL(ivf_accum_kernel, dim3(NSL), dim3(256), lds_c + sizeof(int) * nlist, st, h->X, N, d, assign, nlist, slab, cnt_slab);
     if (it == n_iter) {  // final assignment: only the counts are needed
       hipLaunchKernelGGL(ivf_update_kernel, dim3((nlist * d + 255) / 256), dim3(256), 0, st, slab, cnt_slab, NSL, nlist, d, h->C, counts, 0);
