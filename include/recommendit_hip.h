@@ -91,8 +91,11 @@ int rihip_bpr_pair_loss(const float* U, const float* P, const float* N, int64_t 
  *   rihip_sum_partials  loss = scale * sum(loss_part[0 .. rihip_inbatch_loss_parts))  with scale = 1/(B(B-1))
  * workspace: floats, rihip_inbatch_workspace_floats(n_owner, n_swept, d) (slabs of the swept-range splits that
  * keep small batches chip-filling; combined in fixed order => bitwise reproducible).
- * precision: 0 = exact-f32 MFMA (default, the parity reference); 1 = "bf16x3": operands split hi+lo in bf16,
- * products hi.hi+hi.lo+lo.hi on bf16 MFMA with f32 accumulation (relative product error ~2^-16).
+ * precision: 0 = exact-f32 MFMA (v_mfma_f32_32x32x2_f32, an fmaf chain); 2 = "bf16x6": every fp32 operand split
+ * EXACTLY into three bf16 pieces (8+8+8 bits), six of the nine partial products on bf16 MFMA with f32 accumulation
+ * (dropped terms <= 2^-23 |a||b|: fp32-level accuracy, same test tolerances as precision 0, ~2.5x faster);
+ * 1 = "bf16x3": two pieces, products hi.hi+hi.lo+lo.hi (relative product error ~2^-16).  The stored-G passes take
+ * precision 0 or 2.
  * Global indices (owner_goff / swept_goff) place a rank's local rows inside the all-gathered
  * batch for multi-GPU in-batch negatives; n_global = B.  d in {32,64,128}. */
 int rihip_rowdot(const float* U, const float* I, int64_t B, int64_t i_offset, int d, float* pos, void* stream);
@@ -116,10 +119,10 @@ int64_t rihip_inbatch_gmat_floats(int64_t n_users, int64_t n_items);
 int rihip_inbatch_user_pass(const float* users, int64_t n_users, int64_t user_goff, const float* items,
                             int64_t n_items, int64_t item_goff, int d, const float* pos, int64_t n_global,
                             float* d_users, float* r_out, double* loss_part, float* workspace, float* gmat,
-                            void* stream);
+                            int precision, void* stream);
 int rihip_inbatch_item_pass(const float* gmat, const float* users, int64_t n_users, int64_t user_goff,
                             int64_t n_items, int64_t item_goff, int d, const float* r, int64_t n_global,
-                            float* d_items, float* workspace, void* stream);
+                            float* d_items, float* workspace, int precision, void* stream);
 
 /* ---- optimiser -----------------------------------------------------------------------------
  * clip_grad_norm_(max_norm) (train_embeddings.py:191): rihip_sumsq writes rihip_sumsq_nparts()

@@ -45,8 +45,9 @@ SIGNATURES = {
     "rihip_sum_partials": (C.c_int, [vp, c_i64, C.c_double, vp, vp]),
     "rihip_inbatch_gmat_floats": (c_i64, [c_i64, c_i64]),
     "rihip_inbatch_user_pass": (C.c_int, [vp, c_i64, c_i64, vp, c_i64, c_i64, C.c_int, vp, c_i64, vp, vp, vp, vp, vp,
+                                          C.c_int, vp]),
+    "rihip_inbatch_item_pass": (C.c_int, [vp, vp, c_i64, c_i64, c_i64, c_i64, C.c_int, vp, c_i64, vp, vp, C.c_int,
                                           vp]),
-    "rihip_inbatch_item_pass": (C.c_int, [vp, vp, c_i64, c_i64, c_i64, c_i64, C.c_int, vp, c_i64, vp, vp, vp]),
     "rihip_sumsq_nparts": (C.c_int, []),
     "rihip_sumsq": (C.c_int, [vp, c_i64, vp, vp]),
     "rihip_clip_coef": (C.c_int, [vp, c_i64, C.c_float, vp, vp, vp]),

@@ -15,6 +15,8 @@
 #include "loss_sweep_args.h"
 
 void rihip_launch_sweep_bf16x3(int d, bool mode_user, const SweepArgs& a, dim3 grid, hipStream_t st);
+void rihip_launch_sweep_x6(int d, bool mode_user, const SweepArgs& a, dim3 grid, int nw, hipStream_t st);
+void rihip_launch_gt_x6(int d, const SweepArgs& a, dim3 grid, int nw, hipStream_t st);
 
 namespace {
 
@@ -557,8 +559,8 @@ extern "C" int rihip_inbatch_sweep(int mode_user, const float* owners, int64_t n
                                    const float* r_in, int64_t n_global, float* d_owner, float* r_out,
                                    double* loss_part, float* workspace, int precision, void* stream) {
   RIHIP_REQUIRE(d == 32 || d == 64 || d == 128, RIHIP_ERR_SHAPE, "inbatch_sweep: unsupported embed_dim=%d", d);
-  RIHIP_REQUIRE(precision == 0 || precision == 1, RIHIP_ERR_ARG, "inbatch_sweep: precision=%d (0=f32, 1=bf16x3)",
-                precision);
+  RIHIP_REQUIRE(precision >= 0 && precision <= 2, RIHIP_ERR_ARG,
+                "inbatch_sweep: precision=%d (0=f32 MFMA, 1=bf16x3, 2=bf16x6)", precision);
   RIHIP_REQUIRE(owners && swept && pos && d_owner, RIHIP_ERR_ARG, "inbatch_sweep: null pointer");
   RIHIP_REQUIRE(mode_user ? (r_out && loss_part) : (r_in != nullptr), RIHIP_ERR_ARG,
                 "inbatch_sweep: mode-specific pointer missing");
@@ -579,6 +581,7 @@ extern "C" int rihip_inbatch_sweep(int mode_user, const float* owners, int64_t n
   const dim3 grid((unsigned)((n_owner + nw * 32 - 1) / (nw * 32)), (unsigned)a.nsplit);
   hipStream_t st = (hipStream_t)stream;
   if (precision == 1) rihip_launch_sweep_bf16x3(d, mode_user != 0, a, grid, st);
+  else if (precision == 2) rihip_launch_sweep_x6(d, mode_user != 0, a, grid, nw, st);
   else if (d == 32) launch_sweep<32>(mode_user != 0, a, grid, nw, st);
   else if (d == 64) launch_sweep<64>(mode_user != 0, a, grid, nw, st);
   else launch_sweep<128>(mode_user != 0, a, grid, nw, st);
@@ -601,10 +604,12 @@ extern "C" int64_t rihip_inbatch_gmat_floats(int64_t n_users, int64_t n_items) {
 extern "C" int rihip_inbatch_user_pass(const float* users, int64_t n_users, int64_t user_goff, const float* items,
                                        int64_t n_items, int64_t item_goff, int d, const float* pos, int64_t n_global,
                                        float* d_users, float* r_out, double* loss_part, float* workspace, float* gmat,
-                                       void* stream) {
+                                       int precision, void* stream) {
   RIHIP_REQUIRE(d == 32 || d == 64 || d == 128, RIHIP_ERR_SHAPE, "inbatch_user_pass: unsupported embed_dim=%d", d);
   RIHIP_REQUIRE(users && items && pos && d_users && r_out && loss_part && gmat, RIHIP_ERR_ARG,
                 "inbatch_user_pass: null pointer");
+  RIHIP_REQUIRE(precision == 0 || precision == 2, RIHIP_ERR_ARG,
+                "inbatch_user_pass: precision=%d (0=f32 MFMA, 2=bf16x6)", precision);
   RIHIP_REQUIRE(n_users > 0 && n_items > 0 && n_global >= 2, RIHIP_ERR_ARG,
                 "inbatch_user_pass: sizes users=%lld items=%lld B=%lld", (long long)n_users, (long long)n_items,
                 (long long)n_global);
@@ -620,7 +625,8 @@ extern "C" int rihip_inbatch_user_pass(const float* users, int64_t n_users, int6
   a.r_part = workspace ? workspace + (size_t)a.nsplit * n_users * d : nullptr;
   const dim3 grid((unsigned)((n_users + nw * 32 - 1) / (nw * 32)), (unsigned)a.nsplit);
   hipStream_t st = (hipStream_t)stream;
-  if (d == 32) launch_sweep<32>(true, a, grid, nw, st);
+  if (precision == 2) rihip_launch_sweep_x6(d, true, a, grid, nw, st);
+  else if (d == 32) launch_sweep<32>(true, a, grid, nw, st);
   else if (d == 64) launch_sweep<64>(true, a, grid, nw, st);
   else launch_sweep<128>(true, a, grid, nw, st);
   RIHIP_CHECK_LAUNCH();
@@ -634,9 +640,11 @@ extern "C" int rihip_inbatch_user_pass(const float* users, int64_t n_users, int6
 
 extern "C" int rihip_inbatch_item_pass(const float* gmat, const float* users, int64_t n_users, int64_t user_goff,
                                        int64_t n_items, int64_t item_goff, int d, const float* r, int64_t n_global,
-                                       float* d_items, float* workspace, void* stream) {
+                                       float* d_items, float* workspace, int precision, void* stream) {
   RIHIP_REQUIRE(d == 32 || d == 64 || d == 128, RIHIP_ERR_SHAPE, "inbatch_item_pass: unsupported embed_dim=%d", d);
   RIHIP_REQUIRE(gmat && users && r && d_items, RIHIP_ERR_ARG, "inbatch_item_pass: null pointer");
+  RIHIP_REQUIRE(precision == 0 || precision == 2, RIHIP_ERR_ARG,
+                "inbatch_item_pass: precision=%d (0=f32 MFMA, 2=bf16x6)", precision);
   RIHIP_REQUIRE(n_users > 0 && n_items > 0 && n_global >= 2, RIHIP_ERR_ARG,
                 "inbatch_item_pass: sizes users=%lld items=%lld B=%lld", (long long)n_users, (long long)n_items,
                 (long long)n_global);
@@ -653,7 +661,9 @@ extern "C" int rihip_inbatch_item_pass(const float* gmat, const float* users, in
   a.slab = workspace; a.r_part = nullptr;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)gx, (unsigned)a.nsplit);
-  if (nw == 8) {
+  if (precision == 2) {
+    rihip_launch_gt_x6(d, a, grid, nw, st);
+  } else if (nw == 8) {
     if (d == 32) hipLaunchKernelGGL((inbatch_gt_kernel<32, 8>), grid, dim3(512), 0, st, a);
     else if (d == 64) hipLaunchKernelGGL((inbatch_gt_kernel<64, 8>), grid, dim3(512), 0, st, a);
     else hipLaunchKernelGGL((inbatch_gt_kernel<128, 8>), grid, dim3(512), 0, st, a);

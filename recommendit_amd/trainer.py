@@ -107,7 +107,7 @@ class HipBPRTrainer:
         self.loss_mode, self.table_opt = loss_mode, table_opt
         self.step_count = 0
         self.seed = seed
-        self.inbatch_precision = int(inbatch_precision)  # 0 = exact f32 MFMA, 1 = split-bf16 (bf16x3)
+        self.inbatch_precision = int(inbatch_precision)  # 0 = f32 MFMA, 1 = bf16x3, 2 = bf16x6 (fp32-level accuracy)
         self.inbatch_store_g = inbatch_store_g  # None = auto: store G (no second score sweep) when it fits in HBM
         self.sweep_events = None
         self.use_graph = bool(use_graph)
@@ -192,8 +192,8 @@ class HipBPRTrainer:
             store = self.inbatch_store_g
             if store is None:
                 free_b = torch.cuda.mem_get_info(self.dev)[0]
-                store = self.inbatch_precision == 0 and 4 * ng <= 0.5 * free_b
-            self.inbatch_store_g = bool(store) and self.inbatch_precision == 0
+                store = self.inbatch_precision in (0, 2) and 4 * ng <= 0.5 * free_b
+            self.inbatch_store_g = bool(store) and self.inbatch_precision in (0, 2)
             if self.inbatch_store_g:
                 self.gmat = torch.empty((ng,), **f32)
             if self.world > 1:
@@ -354,15 +354,15 @@ class HipBPRTrainer:
             # the all-gather was started right after the item tower's forward
             self._I_work.wait()
             I_all = self.I_all
-        if self.inbatch_store_g and self.inbatch_precision == 0:
+        if self.inbatch_store_g and self.inbatch_precision in (0, 2):
             # user pass keeps G in HBM; item pass = G^T.U over the local users for all items, reduce-scattered to
             # the rank that owns each item's tower backward (no second score sweep, no U/pos/r gathers)
             self._timed(lib.rihip_inbatch_user_pass, "inbatch_user_pass", self.U.data_ptr(), B, off, I_all.data_ptr(),
                         G, 0, d, self.pos.data_ptr(), G, self.dU.data_ptr(), self.r.data_ptr(), self.lpart.data_ptr(),
-                        self.sws.data_ptr(), self.gmat.data_ptr(), st)
+                        self.sws.data_ptr(), self.gmat.data_ptr(), self.inbatch_precision, st)
             dI_all = self.dI if W == 1 else self.dI_all
             self._timed(lib.rihip_inbatch_item_pass, "inbatch_item_pass", self.gmat.data_ptr(), self.U.data_ptr(), B,
-                        off, G, 0, d, self.r.data_ptr(), G, dI_all.data_ptr(), self.sws.data_ptr(), st)
+                        off, G, 0, d, self.r.data_ptr(), G, dI_all.data_ptr(), self.sws.data_ptr(), self.inbatch_precision, st)
             if W > 1:
                 self._dI_work = reduce_scatter_sum(self.dI, self.dI_all, self.pg, async_op=True)
         elif W == 1:

@@ -204,13 +204,13 @@ def inbatch_loss_and_grads(U: torch.Tensor, I: torch.Tensor, precision: int = 0,
     ng = lib.rihip_inbatch_gmat_floats(B, B)
     if store_g is None:
         store_g = 4 * ng <= (4 << 30)
-    if store_g and precision == 0:
+    if store_g and precision in (0, 2):
         gm = torch.empty((ng,), dtype=torch.float32, device=dev)
         L.check(lib.rihip_inbatch_user_pass(Uc.data_ptr(), B, 0, Ic.data_ptr(), B, 0, d, posv.data_ptr(), B,
                                             dU.data_ptr(), rv.data_ptr(), part.data_ptr(), ws.data_ptr(),
-                                            gm.data_ptr(), st), "inbatch_user_pass")
+                                            gm.data_ptr(), precision, st), "inbatch_user_pass")
         L.check(lib.rihip_inbatch_item_pass(gm.data_ptr(), Uc.data_ptr(), B, 0, B, 0, d, rv.data_ptr(), B, dI.data_ptr(),
-                                            ws.data_ptr(), st), "inbatch_item_pass")
+                                            ws.data_ptr(), precision, st), "inbatch_item_pass")
         L.check(lib.rihip_sum_partials(part.data_ptr(), lib.rihip_inbatch_loss_parts(B, B), 1.0 / (B * (B - 1.0)),
                                        loss.data_ptr(), st), "sum_partials")
         return loss, dU, dI

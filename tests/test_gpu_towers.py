@@ -164,13 +164,14 @@ def test_g3_inbatch_golden(golden_dir, B):
     np.testing.assert_allclose(I.grad.cpu().numpy(), g[f"B{B}_dI"], atol=3e-8, rtol=3e-4)
 
 
+@pytest.mark.parametrize("prec", [0, 2])   # 2 = bf16x6: fp32-level accuracy, held to the SAME tolerances as f32 MFMA
 @pytest.mark.parametrize("B,d", [(33, 32), (130, 64), (500, 128), (1024, 64)])
-def test_inbatch_vs_oracle_ragged_and_reproducible(B, d):
+def test_inbatch_vs_oracle_ragged_and_reproducible(B, d, prec):
     from recommendit_amd.two_tower import inbatch_loss_and_grads
     rng = np.random.RandomState(B)
     U, I = fx.unit_rows(rng, B, d), fx.unit_rows(rng, B, d)
-    l1, dU1, dI1 = inbatch_loss_and_grads(t(U), t(I))
-    l2, dU2, dI2 = inbatch_loss_and_grads(t(U), t(I))
+    l1, dU1, dI1 = inbatch_loss_and_grads(t(U), t(I), precision=prec)
+    l2, dU2, dI2 = inbatch_loss_and_grads(t(U), t(I), precision=prec)
     assert torch.equal(dU1, dU2) and torch.equal(dI1, dI2) and torch.equal(l1, l2)
     lo, dUo, dIo = O.in_batch_bpr_loss(U, I)
     assert abs(l1.item() - float(lo)) < 3e-6
@@ -195,7 +196,8 @@ def test_inbatch_stored_g_equals_recompute_form(B, d):
 
 @pytest.mark.parametrize("Bl,G,off,d", [(100, 300, 100, 64), (64, 256, 192, 128), (37, 111, 0, 32),
                                          (4100, 4230, 77, 64)])   # last: 8-wave workgroups, ragged, split sweeps
-def test_inbatch_stored_g_rectangular_rank_form(Bl, G, off, d):
+@pytest.mark.parametrize("prec", [0, 2])
+def test_inbatch_stored_g_rectangular_rank_form(Bl, G, off, d, prec):
     """Multi-GPU shape of the stored-G passes through the C ABI: local users [Bl] (positives = items off..off+Bl)
     against all G items; the item pass returns this rank's partial dI for ALL items (oracle: rectangular form)."""
     from recommendit_amd import _lib as L
@@ -212,9 +214,9 @@ def test_inbatch_stored_g_rectangular_rank_form(Bl, G, off, d):
     loss = torch.empty((), **f32)
     L.check(lib.rihip_rowdot(Ud.data_ptr(), Id.data_ptr(), Bl, off, d, pos.data_ptr(), st), "rowdot")
     L.check(lib.rihip_inbatch_user_pass(Ud.data_ptr(), Bl, off, Id.data_ptr(), G, 0, d, pos.data_ptr(), G,
-                                        dU.data_ptr(), r.data_ptr(), lp.data_ptr(), ws.data_ptr(), gm.data_ptr(), st), "up")
+                                        dU.data_ptr(), r.data_ptr(), lp.data_ptr(), ws.data_ptr(), gm.data_ptr(), prec, st), "up")
     L.check(lib.rihip_inbatch_item_pass(gm.data_ptr(), Ud.data_ptr(), Bl, off, G, 0, d, r.data_ptr(), G, dI.data_ptr(),
-                                        ws.data_ptr(), st), "ip")
+                                        ws.data_ptr(), prec, st), "ip")
     L.check(lib.rihip_sum_partials(lp.data_ptr(), lib.rihip_inbatch_loss_parts(Bl, G), 1.0 / (G * (G - 1.0)),
                                    loss.data_ptr(), st), "sum")
     lo, dUo, dIo = O.in_batch_bpr_loss(U, I, owner_offset=off, n_global=G)

@@ -5,6 +5,7 @@ from recommendit_amd import _lib as L
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+PREC = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 lib = L.lib(); dev = L.device(); st = L.stream_ptr()
 g = torch.Generator(device="cpu").manual_seed(1)
 U = torch.nn.functional.normalize(torch.randn(B, d, generator=g), dim=1).to(dev)
@@ -24,12 +25,12 @@ def two_sweep():
                                     dI.data_ptr(), None, None, ws.data_ptr(), 0, st), "i")
 def upass():
     L.check(lib.rihip_inbatch_user_pass(U.data_ptr(), B, 0, I.data_ptr(), B, 0, d, pos.data_ptr(), B, dU2.data_ptr(),
-                                        r2.data_ptr(), lp.data_ptr(), ws.data_ptr(), gm.data_ptr(), st), "up")
+                                        r2.data_ptr(), lp.data_ptr(), ws.data_ptr(), gm.data_ptr(), PREC, st), "up")
 def ipass():
     L.check(lib.rihip_inbatch_item_pass(gm.data_ptr(), U.data_ptr(), B, 0, B, 0, d, r2.data_ptr(), B, dI2.data_ptr(),
-                                        ws.data_ptr(), st), "ip")
+                                        ws.data_ptr(), PREC, st), "ip")
 two_sweep(); upass(); ipass(); torch.cuda.synchronize()
-print("dU equal", torch.equal(dU, dU2), "r equal", torch.equal(r, r2),
+print("dU maxrel", float(((dU - dU2).abs() / (dU.abs() + 1e-12)).max()), "dU equal", torch.equal(dU, dU2), "r equal", torch.equal(r, r2),
       "dI maxabs", float((dI - dI2).abs().max()), "scale", float(dI.abs().max()))
 def tm(fn, n=5):
     fn(); torch.cuda.synchronize()
