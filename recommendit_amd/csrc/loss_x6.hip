@@ -67,7 +67,9 @@ struct Planes {
   static constexpr int COLP = D * LDC;      // bf16 per col plane
 };
 
-// Split a staged fp32 tile into LDS planes.  Thread -> row pair rp (rows 2rp, 2rp+1) x CW consecutive columns.
+// Split a staged fp32 tile into LDS planes.  Thread -> row pair rp (rows 2rp, 2rp+1) x CW consecutive columns; the row
+// pair is the fastest index across lanes, so the dword writes into the col planes (one column each, 80-B pitch) land
+// on 16 consecutive dwords x 4 columns = 64 distinct banks per wave.
 template <int D, int NT, bool ROWS, bool PERM>
 struct TileStager {
   static constexpr int CW = (TSW * D) / (2 * NT) >= 4 ? (TSW * D) / (2 * NT) : 4;  // columns per thread (4 or 8)
@@ -76,7 +78,7 @@ struct TileStager {
   f32x4 v[2][NV];
   __device__ __forceinline__ void load(const float* __restrict__ Ys, int64_t Ns, int64_t s_base, int tid) {
     if (tid < NACT) {
-      const int rp = tid / (D / CW), cg = tid % (D / CW);
+      const int rp = tid % (TSW / 2), cg = tid / (TSW / 2);
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int64_t srow = s_base + 2 * rp + e;
@@ -92,7 +94,7 @@ struct TileStager {
   __device__ __forceinline__ void store(__bf16* rowp, __bf16* colp, int tid) const {
     using P = Planes<D>;
     if (tid < NACT) {
-      const int rp = tid / (D / CW), cg = tid % (D / CW);
+      const int rp = tid % (TSW / 2), cg = tid / (TSW / 2);
       uint32_t b[2][CW], c[2][CW], s[2][CW];
 #pragma unroll
       for (int e = 0; e < 2; ++e)
@@ -375,12 +377,21 @@ __global__ __launch_bounds__(NW * 64, 2) void inbatch_gt_x6_kernel(SweepArgs a) 
   TileStager<D, NT, false, false> stg;
   const f32x4* gp = reinterpret_cast<const f32x4*>(a.gmat + ((size_t)(blockIdx.x * NW + w) * a.g_ub) * 1024 +
                                                    r31 * 32 + 16 * hh);
-  f32x4 gc[4], gn[4];  // lane (item, hh): users 16hh .. 16hh+15 of tile / tile+1
+  // G blocks are requested NPF tiles ahead (16 registers per tile in flight): the per-tile compute is short here
+  // (48 bf16 MFMAs), so one tile of lookahead does not cover the HBM latency of the 2+ TB/s stream.
+  constexpr int NPF = 4;
+  f32x4 gq[NPF][4];  // lane (item, hh): users 16hh .. 16hh+15 of tiles tile .. tile+NPF-1 (slot 0 = current)
 #pragma unroll
-  for (int q = 0; q < 4; ++q) gc[q] = gn[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int f = 0; f < NPF; ++f)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gq[f][q] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (t0 < t1) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) gc[q] = gp[(size_t)t0 * 256 + q];
+    for (int f = 0; f < NPF; ++f)
+      if (t0 + f < t1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gq[f][q] = gp[(size_t)(t0 + f) * 256 + q];
+      }
     stg.load(a.Ys, a.Ns, t0 * TSW, tid);
     stg.store(nullptr, colp, tid);
   }
@@ -390,17 +401,22 @@ __global__ __launch_bounds__(NW * 64, 2) void inbatch_gt_x6_kernel(SweepArgs a) 
   for (int64_t tile = t0; tile < t1; ++tile) {
     const int cur = (int)((tile - t0) & 1);
     const bool more = (tile + 1 < t1);
-    if (more) {
-      stg.load(a.Ys, a.Ns, (tile + 1) * TSW, tid);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) gn[q] = gp[(size_t)(tile + 1) * 256 + q];
-    }
+    if (more) stg.load(a.Ys, a.Ns, (tile + 1) * TSW, tid);
     const __bf16* cp_c = colp + cur * 3 * P::COLP;
     float g[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) g[4 * q + s] = gc[q][s];
+      for (int s = 0; s < 4; ++s) g[4 * q + s] = gq[0][q][s];
+    // rotate the ring and request tile + NPF
+#pragma unroll
+    for (int f = 0; f + 1 < NPF; ++f)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gq[f][q] = gq[f + 1][q];
+    if (tile + NPF < t1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gq[NPF - 1][q] = gp[(size_t)(tile + NPF) * 256 + q];
+    }
     u32x4 ga[2][3];  // k-step s <-> users 16hh + 8s + j
     split_regs(g, ga[0], ga[1]);
 #pragma unroll
@@ -415,8 +431,6 @@ __global__ __launch_bounds__(NW * 64, 2) void inbatch_gt_x6_kernel(SweepArgs a) 
       }
     }
     if (more) stg.store(nullptr, colp + (cur ^ 1) * 3 * P::COLP, tid);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) gc[q] = gn[q];
     __syncthreads();
   }
 
