@@ -100,16 +100,18 @@ def _oracle_step(sd, mom, u, p, gp, n, gn, step, lr, mode, sparse):
     return float(loss)
 
 
-@pytest.mark.parametrize("mode,opt,cfg", [("sampled", "sparse", (100, 200, 32, 64, 48)),
-                                          ("inbatch", "dense", (100, 200, 64, 128, 40)),
-                                          ("inbatch", "sparse", (300, 150, 128, 128, 100)),
-                                          ("sampled", "sparse", (60, 30, 64, 128, 256))])   # heavy duplicates
-def test_fused_step_variants_vs_oracle(mode, opt, cfg):
+@pytest.mark.parametrize("mode,opt,cfg,prec", [("sampled", "sparse", (100, 200, 32, 64, 48), 0),
+                                               ("inbatch", "dense", (100, 200, 64, 128, 40), 0),
+                                               ("inbatch", "sparse", (300, 150, 128, 128, 100), 0),
+                                               ("inbatch", "sparse", (300, 150, 128, 128, 100), 2),   # bf16x6 passes
+                                               ("inbatch", "dense", (100, 200, 64, 128, 40), 2),
+                                               ("sampled", "sparse", (60, 30, 64, 128, 256), 0)])  # heavy duplicates
+def test_fused_step_variants_vs_oracle(mode, opt, cfg, prec):
     from recommendit_amd.trainer import HipBPRTrainer
     nu, ni, d, H, B = cfg
     m, sd = _model(nu, ni, d, H, seed=3)
     m.train()
-    tr = HipBPRTrainer(m, B, lr=5e-3, weight_decay=1e-5, loss_mode=mode, table_opt=opt)
+    tr = HipBPRTrainer(m, B, lr=5e-3, weight_decay=1e-5, loss_mode=mode, table_opt=opt, inbatch_precision=prec)
     mom = ({k: np.zeros_like(v) for k, v in sd.items()}, {k: np.zeros_like(v) for k, v in sd.items()})
     for step in range(1, 6):
         u, p, gp, n, gn = fx.make_batch(nu, ni, B, seed=step * 11, boundary=False)
