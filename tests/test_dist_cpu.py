@@ -23,7 +23,7 @@ def _worker(rank, world, port, B, d, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from recommendit_amd.dist_utils import all_gather_into, all_reduce_sum_
+    from recommendit_amd.dist_utils import all_gather_into, all_reduce_sum_, reduce_scatter_sum
     rng = np.random.RandomState(0)
     U, I = fx.unit_rows(rng, world * B, d), fx.unit_rows(rng, world * B, d)
     Ul, Il = U[rank * B:(rank + 1) * B], I[rank * B:(rank + 1) * B]
@@ -35,6 +35,14 @@ def _worker(rank, world, port, B, d, out_dir):
     loss_l, dU_l, _ = O.in_batch_bpr_loss(Ul, I_all.numpy(), owner_offset=rank * B, n_global=world * B)
     _, _, dI_full = O.in_batch_bpr_loss(U_all.numpy(), I_all.numpy())
     dI_l = dI_full[rank * B:(rank + 1) * B]            # what the item-mode sweep of this rank produces
+    # stored-G form: this rank's users give a partial dI for ALL items; reduce-scatter hands every rank the rows of
+    # its own items (async handle API, synchronous on gloo)
+    _, _, dI_part = O.in_batch_bpr_loss(Ul, I_all.numpy(), owner_offset=rank * B, n_global=world * B)
+    dI_rs = torch.empty((B, d))
+    reduce_scatter_sum(dI_rs, torch.from_numpy(dI_part), async_op=True).wait()
+    np.testing.assert_allclose(dI_rs.numpy(), dI_l, atol=1e-9)
+    w = all_gather_into(I_all, torch.from_numpy(Il), async_op=True)
+    w.wait()
     lt = torch.tensor([float(loss_l)], dtype=torch.float64)
     all_reduce_sum_(lt)
     # squared norms of disjoint (user-side) shards add up to the global norm
