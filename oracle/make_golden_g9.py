@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """G9: run the REFERENCE training loop (src/training/train_embeddings.py, unmodified, imported in this
 container only) on the seeded ML-1M-shaped synthetic set and record its loss curve and the
-retrieval-only NDCG under the run_evaluate protocol, for several seeds -> tests/golden/g9_reference_ndcg.json.
+retrieval-only NDCG under the run_evaluate protocol (first 200 test users) AND over all test users (same metric,
+30x less sampling noise), for several seeds -> tests/golden/g9_reference_ndcg.json.
 
 The only shim is an in-process stand-in for the missing `pydantic_settings` package, so that
-`src.config` imports; it carries no logic.  Usage: python oracle/make_golden_g9.py [n_seeds] [epochs]
+`src.config` imports; it carries no logic.  Usage: python oracle/make_golden_g9.py [n_seeds] [epochs] [first_seed] [out_json]   (shards are merged by hand)
 """
 import json
 import sys
@@ -39,12 +40,14 @@ from oracle import metrics_np as M  # noqa: E402
 from oracle import retrieval_np as R  # noqa: E402
 
 
-def evaluate(model, ratings, movies, genre_dict):
+def evaluate(model, ratings, movies, genre_dict, max_users=200):
     """retrieval-only form of src/pipelines/run_pipeline.py:153-230 (exact IP, default features => ranker ties)."""
     n_users = ratings["user_id"].nunique()
     n_test = max(1, int(len(ratings) * 0.1 / n_users))
     test = ratings.sort_values("timestamp").groupby("user_id").tail(n_test)
-    eval_users = test["user_id"].unique()[:200]
+    eval_users = test["user_id"].unique()
+    if max_users:
+        eval_users = eval_users[:max_users]
     item_ids = sorted(movies["item_id"].unique().tolist())
     gm = np.stack([genre_dict.get(i, np.zeros(18, np.float32)) for i in item_ids])
     E = R.normalize_rows(model.get_item_embeddings(item_ids, gm))
@@ -59,6 +62,8 @@ def evaluate(model, ratings, movies, genre_dict):
 def main():
     n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    first_seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    out_path = Path(sys.argv[4]) if len(sys.argv) > 4 else ROOT / "tests" / "golden" / "g9_reference_ndcg.json"
     import logging
     logging.basicConfig(level=logging.INFO)
     from src.training.train_embeddings import EmbeddingTrainer
@@ -67,7 +72,7 @@ def main():
            "embed_dim": 64, "runs": []}
     with tempfile.TemporaryDirectory() as td:
         write_ml1m_files(td, ratings, movies, 6040)
-        for seed in range(n_seeds):
+        for seed in range(first_seed, first_seed + n_seeds):
             torch.manual_seed(seed)
             np.random.seed(seed)
             t0 = time.time()
@@ -87,10 +92,11 @@ def main():
             logging.getLogger("src.training.train_embeddings").removeHandler(h)
             gd = tr._build_item_genre_dict(movies)
             res = evaluate(model, ratings, movies, gd)
+            res.update({k + "_all_users": v for k, v in evaluate(model, ratings, movies, gd, max_users=None).items()})
             res.update(seed=seed, epoch_losses=losses, seconds=time.time() - t0)
             print(json.dumps(res), flush=True)
             out["runs"].append(res)
-            (ROOT / "tests" / "golden" / "g9_reference_ndcg.json").write_text(json.dumps(out, indent=1))
+            out_path.write_text(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":

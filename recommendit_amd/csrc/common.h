@@ -86,6 +86,11 @@ __host__ __device__ __forceinline__ bool rihip_keep(uint64_t seed_mix, uint64_t 
   const uint32_t h = rihip_lowbias32(lo ^ rihip_lowbias32(hi + 0x9E3779B9u));
   return (h >> 8) >= thresh24;
 }
+// same decision for element counters below 2^32 (the upper word of the counter is 0, so the inner hash is a constant
+// of the launch): inner = rihip_lowbias32((uint32_t)(seed_mix >> 32) + 0x9E3779B9u)
+__host__ __device__ __forceinline__ bool rihip_keep32(uint32_t seed_lo, uint32_t inner, uint32_t idx, uint32_t thresh24) {
+  return (rihip_lowbias32((idx ^ seed_lo) ^ inner) >> 8) >= thresh24;
+}
 // the 64-bit seed is scrambled once on the host
 __host__ __device__ __forceinline__ uint64_t rihip_seed_mul(uint64_t seed) { return rihip_splitmix64(seed); }
 static inline uint32_t rihip_thresh24(float p) {

@@ -166,6 +166,7 @@ __global__ __launch_bounds__(256, 2) void tower_fwd_kernel(TowerFwdArgs a) {
   const float b1v = a.b1[ct1 * 32 + (lane & 31)];
   const float b2v = a.b2[ct2 * 32 + (lane & 31)];
   const uint64_t seed_mul = a.seed_step ? rihip_splitmix64(a.seed_mul + (uint64_t)(*a.seed_step)) : a.seed_mul;
+  const uint32_t inner0 = rihip_lowbias32((uint32_t)(seed_mul >> 32) + 0x9E3779B9u);
 
   const int64_t ntiles = (a.B + TM - 1) / TM;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -180,6 +181,10 @@ __global__ __launch_bounds__(256, 2) void tower_fwd_kernel(TowerFwdArgs a) {
       for (int t = 0; t < T1::NR; ++t) acc[t] = zero16();
       gemm_rowA_regB<KB1, T1::NR>(Xs, LDX, T1::rt0(w), w1f, acc, lane);
       const int col = ct1 * 32 + (lane & 31);
+      // dropout counters of this tile fit 32 bits (always, short of 2^32 hidden elements): one hash per element
+      const uint64_t idx0 = (uint64_t)(a.row0 + row_base) * H;
+      const bool idx32 = (idx0 + (uint64_t)TM * H) < (1ull << 32);
+      const uint32_t idx_base = (uint32_t)idx0;
 #pragma unroll
       for (int t = 0; t < T1::NR; ++t) {
 #pragma unroll
@@ -188,7 +193,9 @@ __global__ __launch_bounds__(256, 2) void tower_fwd_kernel(TowerFwdArgs a) {
           const int64_t grow = row_base + row;
           float v = fmaxf(acc[t][r] + b1v, 0.f);
           if (a.training) {
-            const bool keep = rihip_keep(seed_mul, (uint64_t)(a.row0 + grow) * H + col, a.thresh24);
+            bool keep;
+            if (idx32) keep = rihip_keep32((uint32_t)seed_mul, inner0, idx_base + (uint32_t)(row * H + col), a.thresh24);
+            else keep = rihip_keep(seed_mul, (uint64_t)(a.row0 + grow) * H + col, a.thresh24);
             v = keep ? v * a.scale : 0.f;
           }
           Hs[row * LDH + col] = v;

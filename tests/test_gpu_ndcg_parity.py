@@ -4,7 +4,10 @@ trainer are both trained on the same seeded ML-1M-shaped synthetic set with the 
 B=1024, lr=1e-3, 10 epochs, dropout 0.1, one sampled negative per positive, dense Adam + L2 + clip) and scored
 with the reference's run_evaluate protocol in its retrieval-only form.  Both procedures are stochastic
 (different RNG streams for shuffling, negatives and dropout), so the comparison is between seed means:
-|mean NDCG@10 - reference mean| <= max(0.002, spread of the reference's own seeds)."""
+* the reference's own protocol (first 200 test users): |mean NDCG@10 - reference mean| <= max(0.002, spread of the
+  reference's seeds) -- 200 users make single runs noisy (seed spread ~0.009);
+* the same metric over ALL test users (30x less sampling noise): |mean - reference mean| <= 0.002, the tolerance
+  BASELINE.json's north_star states."""
 import json
 
 import numpy as np
@@ -20,19 +23,23 @@ def test_ndcg_and_loss_curve_match_reference_band(golden_dir, tmp_path):
     runs = ref["runs"]
     assert len(runs) >= 2 and ref["epochs"] == 10 and ref["batch_size"] == 1024
     ref_ndcg = np.array([r["ndcg@10"] for r in runs])
+    ref_all = np.array([r["ndcg@10_all_users"] for r in runs])
     ref_loss = np.array([r["epoch_losses"] for r in runs])
     ratings, movies, _ = ml1m_like(seed=0)
-    got_ndcg, got_loss = [], []
-    for seed in range(3):
+    got_ndcg, got_all, got_loss = [], [], []
+    for seed in range(len(runs)):
         tr = EmbeddingTrainer(model_output_path=str(tmp_path / f"tt{seed}.pt"), embed_dim=64, epochs=10, batch_size=1024,
                               learning_rate=1e-3, loss_mode="sampled", table_opt="dense", dropout=0.1, seed=seed)
         model = tr.train(ratings, movies)
         got_loss.append([h["loss"] for h in tr.history])
         got_ndcg.append(retrieval_ndcg(model, ratings, movies)["ndcg@10"])
-    got_ndcg, got_loss = np.array(got_ndcg), np.array(got_loss)
+        got_all.append(retrieval_ndcg(model, ratings, movies, n_eval_users=None)["ndcg@10"])
+    got_ndcg, got_all, got_loss = np.array(got_ndcg), np.array(got_all), np.array(got_loss)
     print("reference NDCG@10:", ref_ndcg, "HIP NDCG@10:", got_ndcg)
+    print("all users: reference", ref_all, ref_all.mean(), "HIP", got_all, got_all.mean())
     print("reference loss:", ref_loss.mean(0).round(4), "HIP loss:", got_loss.mean(0).round(4))
     # training loss curve: every epoch mean within 0.004 of the reference's epoch mean
     np.testing.assert_allclose(got_loss.mean(0), ref_loss.mean(0), atol=4e-3, rtol=0)
     band = max(0.002, float(ref_ndcg.max() - ref_ndcg.min()))
     assert abs(got_ndcg.mean() - ref_ndcg.mean()) <= band, (got_ndcg, ref_ndcg, band)
+    assert abs(got_all.mean() - ref_all.mean()) <= 0.002, (got_all, ref_all)
