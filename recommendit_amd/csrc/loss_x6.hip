@@ -456,22 +456,21 @@ __global__ __launch_bounds__(NW * 64, 2) void inbatch_gt_x6_kernel(SweepArgs a) 
 template <int D>
 constexpr size_t gt_x6_lds() { return 2 * 3 * (size_t)Planes<D>::COLP * 2 + 16; }
 
+// > 64 KB of dynamic LDS must be granted per kernel once (the flag lives in the caller: one per instantiation)
 template <typename K>
-int set_lds(K kernel, size_t bytes) {
-  static bool done = false;  // per instantiation
+void grant_lds(K kernel, size_t bytes, bool& done) {
   if (!done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
-      return 1;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     done = true;
   }
-  return 0;
 }
 
 template <int D, bool MODE_USER, bool GOUT, int NW>
 void launch_one(const SweepArgs& a, dim3 grid, hipStream_t st) {
   auto k = inbatch_sweep_x6_kernel<D, MODE_USER, GOUT, NW>;
   const size_t lds = sweep_x6_lds<D>(NW);
-  set_lds(k, lds);
+  static bool granted = false;
+  grant_lds(k, lds, granted);
   hipLaunchKernelGGL(k, grid, dim3(NW * 64), lds, st, a);
 }
 template <int D, int NW>
@@ -488,7 +487,8 @@ void launch_sweep_d(bool mode_user, const SweepArgs& a, dim3 grid, int nw, hipSt
 template <int D, int NW>
 void launch_gt_one(const SweepArgs& a, dim3 grid, hipStream_t st) {
   auto k = inbatch_gt_x6_kernel<D, NW>;
-  set_lds(k, gt_x6_lds<D>());
+  static bool granted = false;
+  grant_lds(k, gt_x6_lds<D>(), granted);
   hipLaunchKernelGGL(k, grid, dim3(NW * 64), gt_x6_lds<D>(), st, a);
 }
 template <int D>
