@@ -129,6 +129,15 @@ int rihip_inbatch_item_pass(const float* gmat, const float* users, int64_t n_use
  * partial sums of x^2 per call; rihip_clip_coef reduces any number of partials to
  * coef = min(1, max_norm/(norm+1e-6)) ON DEVICE (no host sync), consumed by the Adam kernels. */
 int rihip_sumsq_nparts(void);
+/* Multi-tensor forms of rihip_sumsq / rihip_adam_dense for steps that are bounded by dependent kernel boundaries
+ * (batch 256 ... 8192 at ML-1M scale): up to 4 tensors per launch, HOST arrays of device pointers and sizes; the
+ * arithmetic and the partial layout (rihip_sumsq_nparts() doubles per tensor, consecutively) equal the single calls.
+ * zero_grad_mask bit t: tensor t's gradient is overwritten with zeros after the update (dense table gradients). */
+int rihip_sumsq_multi(int n_tensors, const float* const* x, const int64_t* n, double* part, void* stream);
+int rihip_adam_dense_multi(int n_tensors, float* const* p, float* const* g, float* const* m, float* const* v,
+                           const int64_t* n, int zero_grad_mask, float lr, float beta1, float beta2, float eps,
+                           float weight_decay, int64_t step, const float* clip_coef, const float* hyper_dev,
+                           void* stream);
 int rihip_sumsq(const float* x, int64_t n, double* part, void* stream);
 int rihip_clip_coef(const double* part, int64_t n_part, float max_norm, float* coef, float* total_norm, void* stream);
 /* torch.optim.Adam(lr, betas, eps, weight_decay) single step with coupled L2

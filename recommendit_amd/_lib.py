@@ -49,6 +49,9 @@ SIGNATURES = {
     "rihip_inbatch_item_pass": (C.c_int, [vp, vp, c_i64, c_i64, c_i64, c_i64, C.c_int, vp, c_i64, vp, vp, C.c_int,
                                           vp]),
     "rihip_sumsq_nparts": (C.c_int, []),
+    "rihip_sumsq_multi": (C.c_int, [C.c_int, vp, vp, vp, vp]),
+    "rihip_adam_dense_multi": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_float, C.c_float, C.c_float,
+                                         C.c_float, C.c_float, c_i64, vp, vp, vp]),
     "rihip_sumsq": (C.c_int, [vp, c_i64, vp, vp]),
     "rihip_clip_coef": (C.c_int, [vp, c_i64, C.c_float, vp, vp, vp]),
     "rihip_adam_dense": (C.c_int, [vp, vp, vp, vp, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, c_i64,

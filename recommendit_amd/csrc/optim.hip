@@ -223,6 +223,73 @@ constexpr int ROWS_GRID = 1024;
 
 }  // namespace
 
+// ---- multi-tensor forms (small-batch steps are bounded by dependent kernel boundaries: one launch for up to 4
+// tensors; blockIdx.y picks the tensor, the arithmetic and the partial layout equal the single-tensor calls)
+struct MultiDesc {
+  float* p[4];
+  float* g[4];
+  float* m[4];
+  float* v[4];
+  int64_t n[4];
+  int zero_grad_mask;
+};
+__global__ __launch_bounds__(256) void sumsq_multi_kernel(MultiDesc d, double* part) {
+  const int t = blockIdx.y;
+  const float* __restrict__ x = d.g[t];
+  const int64_t n = d.n[t];
+  double acc = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t n4 = n / 4;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const f32x4 v = x4[i];
+    acc += (double)(v.x * v.x + v.y * v.y) + (double)(v.z * v.z + v.w * v.w);
+  }
+  if (blockIdx.x == 0) {
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 256) acc += (double)x[i] * (double)x[i];
+  }
+  acc = wave_sum_d(acc);
+  __shared__ double sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[(size_t)t * NPART + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ __launch_bounds__(256) void adam_dense_multi_kernel(MultiDesc d, const float* coef_dev, AdamHyper h,
+                                                               const float* hyper_dev) {
+  const int t = blockIdx.y;
+  if (hyper_dev) { h.lr_over_bc1 = hyper_dev[0]; h.sqrt_bc2 = hyper_dev[1]; }
+  const float coef = coef_dev ? *coef_dev : 1.f;
+  const bool zg = (d.zero_grad_mask >> t) & 1;
+  float* __restrict__ p = d.p[t];
+  float* __restrict__ g = d.g[t];
+  float* __restrict__ m = d.m[t];
+  float* __restrict__ v = d.v[t];
+  const int64_t n = d.n[t];
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t n4 = n / 4;
+  f32x4* p4 = reinterpret_cast<f32x4*>(p);
+  f32x4* g4 = reinterpret_cast<f32x4*>(g);
+  f32x4* m4 = reinterpret_cast<f32x4*>(m);
+  f32x4* v4 = reinterpret_cast<f32x4*>(v);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    f32x4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float pk = pp[k], mk = mm[k], vk = vv[k];
+      adam_elem(pk, gg[k], mk, vk, coef, h);
+      pp[k] = pk; mm[k] = mk; vv[k] = vk;
+    }
+    p4[i] = pp; m4[i] = mm; v4[i] = vv;
+    if (zg) g4[i] = f32x4{0.f, 0.f, 0.f, 0.f};  // the dense table gradient is consumed: next step scatters into zeros
+  }
+  if (blockIdx.x == 0) {
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 256) {
+      adam_elem(p[i], g[i], m[i], v[i], coef, h);
+      if (zg) g[i] = 0.f;
+    }
+  }
+}
+
 extern "C" int rihip_sumsq_nparts(void) { return NPART; }
 extern "C" int rihip_rows_nparts(void) { return ROWS_GRID; }
 
@@ -230,6 +297,48 @@ extern "C" int rihip_sumsq(const float* x, int64_t n, double* part, void* stream
   RIHIP_REQUIRE(x && part && n >= 0, RIHIP_ERR_ARG, "sumsq: bad arguments");
   RIHIP_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, RIHIP_ERR_ARG, "sumsq: x must be 16-byte aligned");
   hipLaunchKernelGGL(sumsq_kernel, dim3(NPART), dim3(256), 0, (hipStream_t)stream, x, n, part);
+  RIHIP_CHECK_LAUNCH();
+  return RIHIP_OK;
+}
+
+extern "C" int rihip_sumsq_multi(int n_tensors, const float* const* x, const int64_t* n, double* part, void* stream) {
+  RIHIP_REQUIRE(n_tensors >= 1 && n_tensors <= 4 && x && n && part, RIHIP_ERR_ARG, "sumsq_multi: bad arguments");
+  MultiDesc d;
+  memset(&d, 0, sizeof(d));
+  for (int t = 0; t < n_tensors; ++t) {
+    RIHIP_REQUIRE(x[t] && n[t] >= 0 && (reinterpret_cast<uintptr_t>(x[t]) & 15) == 0, RIHIP_ERR_ARG,
+                  "sumsq_multi: tensor %d null, negative size or not 16-byte aligned", t);
+    d.g[t] = const_cast<float*>(x[t]);
+    d.n[t] = n[t];
+  }
+  hipLaunchKernelGGL(sumsq_multi_kernel, dim3(NPART, n_tensors), dim3(256), 0, (hipStream_t)stream, d, part);
+  RIHIP_CHECK_LAUNCH();
+  return RIHIP_OK;
+}
+
+extern "C" int rihip_adam_dense_multi(int n_tensors, float* const* p, float* const* g, float* const* m,
+                                      float* const* v, const int64_t* n, int zero_grad_mask, float lr, float beta1,
+                                      float beta2, float eps, float weight_decay, int64_t step,
+                                      const float* clip_coef, const float* hyper_dev, void* stream) {
+  RIHIP_REQUIRE(n_tensors >= 1 && n_tensors <= 4 && p && g && m && v && n && (step >= 1 || hyper_dev), RIHIP_ERR_ARG,
+                "adam_dense_multi: bad arguments");
+  MultiDesc d;
+  memset(&d, 0, sizeof(d));
+  int64_t nmax = 0;
+  for (int t = 0; t < n_tensors; ++t) {
+    RIHIP_REQUIRE(p[t] && g[t] && m[t] && v[t] && n[t] >= 0, RIHIP_ERR_ARG, "adam_dense_multi: tensor %d null", t);
+    RIHIP_REQUIRE(((reinterpret_cast<uintptr_t>(p[t]) | reinterpret_cast<uintptr_t>(g[t]) |
+                    reinterpret_cast<uintptr_t>(m[t]) | reinterpret_cast<uintptr_t>(v[t])) & 15) == 0,
+                  RIHIP_ERR_ARG, "adam_dense_multi: pointers must be 16-byte aligned");
+    d.p[t] = p[t]; d.g[t] = g[t]; d.m[t] = m[t]; d.v[t] = v[t]; d.n[t] = n[t];
+    if (n[t] > nmax) nmax = n[t];
+  }
+  d.zero_grad_mask = zero_grad_mask;
+  if (nmax == 0) return RIHIP_OK;
+  const int64_t nb = (nmax / 4 + 255) / 256;
+  const int grid = (int)(nb < 1 ? 1 : (nb < 2048 ? nb : 2048));
+  hipLaunchKernelGGL(adam_dense_multi_kernel, dim3(grid, n_tensors), dim3(256), 0, (hipStream_t)stream, d, clip_coef,
+                     make_hyper(lr, beta1, beta2, eps, weight_decay, step >= 1 ? step : 1), hyper_dev);
   RIHIP_CHECK_LAUNCH();
   return RIHIP_OK;
 }

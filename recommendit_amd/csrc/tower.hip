@@ -561,7 +561,9 @@ extern "C" int rihip_tower_forward(const float* table, int64_t n_rows, const int
   const bool item = genres != nullptr;
   hipStream_t st = (hipStream_t)stream;
   a.W1p = nullptr; a.W2p = nullptr;
-  if (workspace) {  // re-pack the (just updated) weights fragment-major: 2 tiny launches, coalesced loads in the kernel
+  // re-pack the (just updated) weights fragment-major: 2 tiny launches, coalesced loads in the kernel -- only worth
+  // it when many workgroups load them; a small batch is bounded by dependent kernel boundaries instead
+  if (workspace && ntiles > 64) {
     const int K1 = d + (item ? 18 : 0), KB1 = (K1 + 7) / 8, KB2 = hidden / 8;
     RIHIP_REQUIRE(aligned16(workspace), RIHIP_ERR_ARG, "tower_forward: workspace must be 16-byte aligned");
     f32x4* w1p = reinterpret_cast<f32x4*>(workspace);
@@ -616,7 +618,10 @@ extern "C" int rihip_tower_backward(const float* table, int64_t n_rows, const in
   const int P = hidden * K1 + hidden + d * hidden + d;
   const int G = grid < SLAB_GROUPS ? grid : SLAB_GROUPS;
   float* part = workspace + (size_t)grid * P;
-  hipLaunchKernelGGL(slab_reduce1_kernel, dim3((P + 255) / 256, G), dim3(256), 0, st, workspace, grid, P, G, part);
+  if (grid > SLAB_GROUPS)
+    hipLaunchKernelGGL(slab_reduce1_kernel, dim3((P + 255) / 256, G), dim3(256), 0, st, workspace, grid, P, G, part);
+  else
+    part = workspace;  // at most SLAB_GROUPS slabs: level 1 would be a copy (same summation order either way)
   hipLaunchKernelGGL(slab_reduce2_kernel, dim3((P + 255) / 256), dim3(256), 0, st, part, G, P, hidden, K1, d, dW1, db1,
                      dW2, db2, accumulate);
   RIHIP_CHECK_LAUNCH();

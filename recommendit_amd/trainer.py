@@ -24,6 +24,8 @@ from __future__ import annotations
 import math
 from typing import Dict, Optional
 
+import ctypes as C
+
 import torch
 import torch.distributed as dist
 
@@ -153,6 +155,14 @@ class HipBPRTrainer:
             assert self.world == 1, "dense table optimiser is single-GPU (parity mode)"
             self.uopt = _DenseOpt(self.utab)
             self.iopt = _DenseOpt(self.itab)
+            # host arrays of device pointers for the multi-tensor launches: [MLP flat buffer, user table, item table]
+            PA, NA = C.c_void_p * 3, C.c_int64 * 3
+            ts = [(self.flat_p, self.flat_g, self.flat_m, self.flat_v),
+                  (self.utab, self.uopt.grad, self.uopt.m, self.uopt.v),
+                  (self.itab, self.iopt.grad, self.iopt.m, self.iopt.v)]
+            self._mt_p = PA(*[x[0].data_ptr() for x in ts]); self._mt_g = PA(*[x[1].data_ptr() for x in ts])
+            self._mt_m = PA(*[x[2].data_ptr() for x in ts]); self._mt_v = PA(*[x[3].data_ptr() for x in ts])
+            self._mt_n = NA(*[x[0].numel() for x in ts])
 
         # ---- per-step buffers
         f32 = dict(dtype=torch.float32, device=self.dev)
@@ -301,7 +311,9 @@ class HipBPRTrainer:
             all_reduce_sum_(self.flat_g, self.pg)
             iid, dXi = self.iid_all, self.dXi_all
         pp = self.part.data_ptr()
-        L.check(lib.rihip_sumsq(self.flat_g.data_ptr(), self.flat_g.numel(), pp, st), "sumsq")
+        dense = self.table_opt == "dense"
+        if not dense:
+            L.check(lib.rihip_sumsq(self.flat_g.data_ptr(), self.flat_g.numel(), pp, st), "sumsq")
         o1 = self.np_mlp
         o2 = o1 + self.np_rows
         if self.table_opt == "sparse":
@@ -310,8 +322,9 @@ class HipBPRTrainer:
                 w_i.wait(); w_x.wait()
             self.iopt.group_reduce(iid, dXi, pp + 8 * o2, st)
         else:
-            self.uopt.scatter(user_ids, self.dXu, st); self.uopt.sumsq(pp + 8 * o1, st)
-            self.iopt.scatter(iid, dXi, st); self.iopt.sumsq(pp + 8 * o2, st)
+            # dense tables (ML-1M scale): the table gradients were zeroed by the previous step's Adam launch
+            self.uopt.scatter(user_ids, self.dXu, st, zero=False)
+            self.iopt.scatter(iid, dXi, st, zero=False)
         n_part = o2 + self.np_rows
         if self.world > 1:
             # user rows are disjoint across ranks: their squared norms add; MLP and (replicated) item
@@ -320,13 +333,19 @@ class HipBPRTrainer:
             all_reduce_sum_(usq, self.pg)
             self.part[o1:o2].zero_()
             self.part[o1] = usq[0]
+        if dense:   # one launch for the three squared norms (MLP, user table, item table gradients)
+            L.check(lib.rihip_sumsq_multi(3, self._mt_g, self._mt_n, pp, st), "sumsq_multi")
         L.check(lib.rihip_clip_coef(pp, n_part, self.max_norm, self.coef.data_ptr(), self.gnorm.data_ptr(), st),
                 "clip_coef")
         cp = self.coef.data_ptr()
+        hp = self.hyper_dev.data_ptr()
+        if dense:   # one Adam launch for MLP + both tables; it leaves the table gradients zeroed for the next scatter
+            L.check(lib.rihip_adam_dense_multi(3, self._mt_p, self._mt_g, self._mt_m, self._mt_v, self._mt_n, 0b110, lr,
+                                               self.b1, self.b2, self.eps, self.wd, t, cp, hp, st), "adam_dense_multi")
+            return self.loss
         L.check(lib.rihip_adam_dense(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
                                      self.flat_v.data_ptr(), self.flat_p.numel(), lr, self.b1, self.b2, self.eps,
-                                     self.wd, t, cp, self.hyper_dev.data_ptr(), st), "adam_dense")
-        hp = self.hyper_dev.data_ptr()
+                                     self.wd, t, cp, hp, st), "adam_dense")
         self.uopt.adam(lr, self.b1, self.b2, self.eps, self.wd, t, cp, st, hp)
         self.iopt.adam(lr, self.b1, self.b2, self.eps, self.wd, t, cp, st, hp)
         return self.loss
