@@ -260,6 +260,39 @@ def test_inbatch_full_size_properties():
     np.testing.assert_allclose(dU[:64].cpu().numpy(), dUo, atol=1e-10, rtol=5e-4)
 
 
+@pytest.mark.parametrize("prec", [0, 2])
+def test_inbatch_headline_size_properties(prec):
+    """BASELINE.json's headline shape (global batch 65 536, d = 128; 17 GB of stored G) through size-independent
+    properties and oracle checks on slices: rows of G sum to zero (the item gradients sum to the null vector);
+    <dI, I> == <dU, U> (both are sum_ij G_ij s_ij); the first 64 users against the rectangular oracle; the last 32
+    items against an fp64 G^T.U over ALL users, whose residual must be the diagonal term -r_j u_j (r_j > 0)."""
+    from recommendit_amd.two_tower import inbatch_loss_and_grads
+    rng = np.random.RandomState(11)
+    B, d = 65536, 128
+    U, I = fx.unit_rows(rng, B, d), fx.unit_rows(rng, B, d)
+    Ud, Id = t(U), t(I)
+    loss, dU, dI = inbatch_loss_and_grads(Ud, Id, precision=prec, store_g=True)
+    assert 0.6 < loss.item() < 0.8            # random unit vectors: softplus(z), z ~ N(0, 2/d)
+    assert dI.sum(0).abs().max().item() < 2e-7
+    # <dI, I> = sum_ij G_ij (u_i . i_j) = <dU, U>   (G includes the diagonal entries)
+    a = (dI.double() * Id.to(dI.device).double()).sum().item()
+    b = (dU.double() * Ud.to(dU.device).double()).sum().item()
+    assert abs(a - b) <= 1e-6 * max(abs(a), abs(b), 1e-12) + 1e-12, (a, b)
+    lo, dUo, _ = O.in_batch_bpr_loss(U[:64], I, owner_offset=0, n_global=B)
+    np.testing.assert_allclose(dU[:64].cpu().numpy(), dUo, atol=1e-12, rtol=5e-4)
+    # a column slice of dI against the dense oracle restricted to those items needs all users: do it for 32 items
+    S = U.astype(np.float64) @ I[-32:].astype(np.float64).T                    # [B, 32]
+    pos = (U.astype(np.float64) * I.astype(np.float64)).sum(1)[:, None]
+    G = 1.0 / (1.0 + np.exp(-(S - pos))) / (B * (B - 1.0))
+    G[np.arange(B - 32, B), np.arange(32)] = 0.0
+    dI_off = G.T @ U.astype(np.float64)                                        # off-diagonal part of dI[-32:]
+    # dI_j = dI_off_j - r_j u_j with r_j > 0: the residual must be a negative multiple of u_j
+    res = dI[-32:].double().cpu().numpy() - dI_off
+    coef = (res * U[-32:]).sum(1)
+    assert (coef < 0).all()
+    np.testing.assert_allclose(res, coef[:, None] * U[-32:], atol=2e-10, rtol=0)
+
+
 def test_g4_train50_golden_with_stock_adam(golden_dir):
     """Drop-in check: stock torch.optim.Adam + clip_grad_norm_ + CosineAnnealingLR drive the HIP model
     exactly like the reference loop (train_embeddings.py:183-197)."""
