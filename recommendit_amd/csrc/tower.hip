@@ -12,8 +12,10 @@
 //
 // k-permutation: one ds_read_b128 fetches 4 consecutive k of a row; MFMA step s of an 8-wide
 // k-block uses k = 8*kb + 4*(lane>>5) + s for BOTH operands, so A needs one b128 per 4 MFMAs.
+#include <stdlib.h>
 #include "common.h"
 #include "recommendit_hip.h"
+#include "tower_args.h"
 
 namespace {
 
@@ -89,25 +91,6 @@ __global__ void pack_frag_rows_kernel(const float* __restrict__ W, int N, int K,
   Wp[i] = v;
 }
 
-struct TowerFwdArgs {
-  const f32x4 *W1p, *W2p;  // fragment-major weights (null => strided loads from W1/W2)
-  const float* table;
-  int64_t n_rows;
-  const int64_t* ids;
-  const float* genres;  // [B,18] or null
-  int64_t B;
-  const float *W1, *b1, *W2, *b2;
-  float* out;    // [B,D]
-  float* hid;    // [B,H] post-dropout hidden (nullable)
-  float* denom;  // [B] max(|y|,eps) (nullable)
-  int training;
-  uint64_t seed_mul;
-  uint32_t thresh24;
-  float scale;      // 1/(1-p)
-  int64_t row0;     // global row offset for the dropout counter
-  const int64_t* seed_step;  // optional device step counter mixed into the dropout seed (graph replay)
-  int* err_flag;    // set to 1 on out-of-range id (nullable)
-};
 
 template <int D, int K1P, bool ITEM>
 __device__ __forceinline__ void gather_tile(float* Xs, int ldx, const float* __restrict__ table, int64_t n_rows,
@@ -561,6 +544,14 @@ extern "C" int rihip_tower_forward(const float* table, int64_t n_rows, const int
   const bool item = genres != nullptr;
   hipStream_t st = (hipStream_t)stream;
   a.W1p = nullptr; a.W2p = nullptr;
+  {  // wave-per-32-rows kernel (tower2.hip): weights in LDS, activations in registers, no barrier in the row loop
+    static const char* ev = getenv("RIHIP_TOWER_FWD");
+    const int which = ev ? atoi(ev) : 2;
+    if (which == 2 && rihip_launch_tower_fwd2(d, hidden, item, a, st)) {
+      RIHIP_CHECK_LAUNCH();
+      return RIHIP_OK;
+    }
+  }
   // re-pack the (just updated) weights fragment-major: 2 tiny launches, coalesced loads in the kernel -- only worth
   // it when many workgroups load them; a small batch is bounded by dependent kernel boundaries instead
   if (workspace && ntiles > 64) {
