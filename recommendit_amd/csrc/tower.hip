@@ -547,7 +547,8 @@ extern "C" int rihip_tower_forward(const float* table, int64_t n_rows, const int
   {  // wave-per-32-rows kernel (tower2.hip): weights in LDS, activations in registers, no barrier in the row loop
     static const char* ev = getenv("RIHIP_TOWER_FWD");
     const int which = ev ? atoi(ev) : 2;
-    if (which == 2 && rihip_launch_tower_fwd2(d, hidden, item, a, st)) {
+    if (which == 2 && aligned16(W2) && (reinterpret_cast<uintptr_t>(W1) & 7) == 0 &&
+        rihip_launch_tower_fwd2(d, hidden, item, a, st)) {
       RIHIP_CHECK_LAUNCH();
       return RIHIP_OK;
     }
