@@ -153,11 +153,12 @@ int rihip_adam_hyper_step(int64_t* step_dev, const float* lr_dev, float beta1, f
 /* Row-sparse path for tables too large for a dense pass per step (SURVEY.md §7 hard part 1):
  * group (id,sample) pairs by id (radix sort), sum each row's contributions in sorted order
  * (bitwise reproducible), then Adam on touched rows only.  workspace bytes from
- * rihip_rows_workspace_bytes(B, d); uniq int64[B]; Gc float[B,d]; part double[rihip_rows_nparts()]. */
+ * rihip_rows_workspace_bytes(B, d); uniq int64[B]; Gc float[B,d]; part double[rihip_rows_nparts()].
+ * n_rows: number of table rows (ids < n_rows) -- only the significant key bits are sorted; 0 = unknown (all 63). */
 int64_t rihip_rows_workspace_bytes(int64_t B, int d);
 int rihip_rows_nparts(void);
-int rihip_rows_group(const int64_t* ids, int64_t B, int d, int64_t* uniq, void* workspace, int64_t workspace_bytes,
-                     void* stream);
+int rihip_rows_group(const int64_t* ids, int64_t B, int d, int64_t n_rows, int64_t* uniq, void* workspace,
+                     int64_t workspace_bytes, void* stream);
 int rihip_rows_n_unique_ptr(void* workspace, int64_t B, int d, const int** n_unique_dev);
 int rihip_rows_reduce(const float* dX, int64_t B, int d, const int64_t* uniq, void* workspace, float* Gc,
                       double* part, void* stream);

@@ -59,7 +59,7 @@ SIGNATURES = {
     "rihip_adam_hyper_step": (C.c_int, [vp, vp, C.c_float, C.c_float, vp, vp]),
     "rihip_rows_workspace_bytes": (c_i64, [c_i64, C.c_int]),
     "rihip_rows_nparts": (C.c_int, []),
-    "rihip_rows_group": (C.c_int, [vp, c_i64, C.c_int, vp, vp, c_i64, vp]),
+    "rihip_rows_group": (C.c_int, [vp, c_i64, C.c_int, c_i64, vp, vp, c_i64, vp]),
     "rihip_rows_n_unique_ptr": (C.c_int, [vp, c_i64, C.c_int, C.POINTER(vp)]),
     "rihip_rows_reduce": (C.c_int, [vp, c_i64, C.c_int, vp, vp, vp, vp, vp]),
     "rihip_adam_rows": (C.c_int, [vp, vp, vp, vp, vp, c_i64, C.c_int, vp, C.c_float, C.c_float, C.c_float, C.c_float,

@@ -419,7 +419,7 @@ extern "C" int64_t rihip_rows_workspace_bytes(int64_t B, int d) {
 
 // Groups the B (id, sample) pairs by id.  Outputs (device): uniq[<=B] unique ids ascending,
 // and inside the workspace perm / seg_start / n_unique used by rihip_rows_reduce / rihip_adam_rows.
-extern "C" int rihip_rows_group(const int64_t* ids, int64_t B, int d, int64_t* uniq, void* workspace,
+extern "C" int rihip_rows_group(const int64_t* ids, int64_t B, int d, int64_t n_rows, int64_t* uniq, void* workspace,
                                 int64_t workspace_bytes, void* stream) {
   RIHIP_REQUIRE(ids && uniq && workspace && B > 0 && B < (1ll << 31), RIHIP_ERR_ARG, "rows_group: bad arguments");
   RowsWs ws;
@@ -431,7 +431,12 @@ extern "C" int rihip_rows_group(const int64_t* ids, int64_t B, int d, int64_t* u
   hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(256), 0, st, ws.vals_in, B);
   RIHIP_CHECK_LAUNCH();
   size_t tb = ws.temp_bytes;
-  RIHIP_CHECK_HIP(rocprim::radix_sort_pairs(ws.temp, tb, ids, ws.keys_out, ws.vals_in, ws.perm, (size_t)B, 0, 64, st));
+  unsigned end_bit = 64;  // ids are non-negative row numbers < n_rows: sort only the bits that can differ
+  if (n_rows > 0) {
+    end_bit = 1;
+    while (end_bit < 63 && (1ll << end_bit) < n_rows) ++end_bit;
+  }
+  RIHIP_CHECK_HIP(rocprim::radix_sort_pairs(ws.temp, tb, ids, ws.keys_out, ws.vals_in, ws.perm, (size_t)B, 0, end_bit, st));
   hipLaunchKernelGGL(head_flags_kernel, dim3(nb), dim3(256), 0, st, ws.keys_out, B, ws.flags);
   RIHIP_CHECK_LAUNCH();
   tb = ws.temp_bytes;

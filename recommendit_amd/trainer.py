@@ -59,7 +59,7 @@ class _RowsOpt:
         lib = L.lib()
         B = ids.numel()
         assert B <= self.max_ids
-        L.check(lib.rihip_rows_group(ids.data_ptr(), B, self.d, self.uniq.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
+        L.check(lib.rihip_rows_group(ids.data_ptr(), B, self.d, self.table.shape[0], self.uniq.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
                                      st),
                 "rows_group")
         L.check(lib.rihip_rows_reduce(dX.data_ptr(), B, self.d, self.uniq.data_ptr(), self.ws.data_ptr(),
