@@ -33,6 +33,19 @@ struct Node {  // 32 bytes
   int pad0, pad1;
 };
 
+// Compact node: numerical split only.  x <= thr (double) for an f32 x is the same as x <= thr32 with thr32 the largest
+// f32 not above thr, so the comparison is exact in f32; children are tree-local int8 (>= 0 internal, < 0 => ~leaf).
+struct Node8 {
+  float thr;
+  int8_t left, right;
+  uint8_t feat;
+  uint8_t flags;  // bit0 default_left, bits1-2 missing type (0 none, 1 zero, 2 NaN)
+};
+static_assert(sizeof(Node8) == 8, "Node8 must be 8 bytes");
+constexpr int N8_CAP = 2048;   // compact nodes per chunk (16 KB of LDS)
+constexpr int L8_CAP = 2112;   // leaves per chunk (16.5 KB)
+constexpr int T8_CAP = 32;     // trees per chunk (8 per wave)
+
 constexpr int NODE_CAP = 1280;  // nodes per chunk staged in LDS (40 KB)
 constexpr int LEAF_CAP = 1536;  // leaves per chunk staged in LDS (12 KB)
 constexpr int F_MAX = 128;      // features staged per candidate tile (64 x F x 4 B <= 32 KB)
@@ -53,6 +66,12 @@ struct Forest {
   int *d_tree_node_off = nullptr, *d_tree_leaf_off = nullptr, *d_tree_root = nullptr, *d_chunk = nullptr;
   int *d_cat_b = nullptr, *d_cat_w = nullptr, *d_tree_cat_b_off = nullptr, *d_tree_cat_w_off = nullptr;
   double* d_part = nullptr; int64_t part_elems = 0;
+  // compact form (all-numerical forests whose trees have <= 127 internal nodes): 8-byte nodes, f32 thresholds
+  bool compact = false;
+  std::vector<Node8> nodes8;
+  std::vector<int> chunk8;  // [n_chunks8+1] tree starts
+  Node8* d_nodes8 = nullptr; int* d_chunk8 = nullptr;
+  float zero_thr32 = 0.f;
 };
 
 struct PredArgs {
@@ -128,6 +147,62 @@ __global__ __launch_bounds__(256) void gbdt_predict_kernel(PredArgs a) {
   if (w == 0 && row < a.n) a.part[(size_t)chunk * a.n + row] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
 
+// Compact-forest traversal: 8-byte nodes, exact f32 comparisons, dynamic LDS sized to the forest chunk and the feature
+// count (47 KB at 50 features => 3 workgroups per CU instead of 1: the walk is a chain of dependent LDS reads, so
+// resident waves are what hides its latency).  Same per-wave tree order and same reduction as the general kernel.
+struct Pred8Args {
+  const Node8* nodes; const double* leaves;
+  const int *tree_node_off, *tree_leaf_off, *tree_root, *chunk;
+  const float* X; int64_t n; int F; int ldx;
+  float zero_thr;
+  double* part;
+};
+__global__ __launch_bounds__(256, 3) void gbdt_predict8_kernel(Pred8Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
+  Node8* nS = reinterpret_cast<Node8*>(smem8);                   // [N8_CAP]
+  double* lS = reinterpret_cast<double*>(nS + N8_CAP);           // [L8_CAP]
+  double* red = lS + L8_CAP;                                     // [4][64]
+  float* xS = reinterpret_cast<float*>(red + 4 * 64);            // [F][64] transposed
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int chunk = blockIdx.y;
+  const int t0 = a.chunk[chunk], t1 = a.chunk[chunk + 1];
+  const int n0 = a.tree_node_off[t0], n1 = a.tree_node_off[t1];
+  const int l0 = a.tree_leaf_off[t0], l1 = a.tree_leaf_off[t1];
+  {
+    const uint2* src = reinterpret_cast<const uint2*>(a.nodes + n0);
+    uint2* dst = reinterpret_cast<uint2*>(nS);
+    for (int i = tid; i < (n1 - n0); i += 256) dst[i] = src[i];
+    for (int i = tid; i < (l1 - l0); i += 256) lS[i] = a.leaves[l0 + i];
+  }
+  const int64_t row = (int64_t)blockIdx.x * 64 + lane;
+  for (int i = tid; i < 64 * a.F; i += 256) {
+    const int r = i / a.F, f = i % a.F;
+    const int64_t gr = (int64_t)blockIdx.x * 64 + r;
+    xS[f * 64 + r] = (gr < a.n) ? a.X[gr * a.ldx + f] : 0.f;
+  }
+  __syncthreads();
+  double acc = 0.0;
+  for (int t = t0 + w; t < t1; t += 4) {
+    const Node8* nodes = nS + (a.tree_node_off[t] - n0);
+    int node = a.tree_root[t];
+    while (node >= 0) {
+      const Node8 nd = nodes[node];
+      const float x = xS[nd.feat * 64 + lane];
+      const int m = (nd.flags >> 1) & 3;
+      const bool is_nan = x != x;
+      const float f = (is_nan && m != 2) ? 0.f : x;
+      const bool miss = (m == 1) ? (fabsf(f) <= a.zero_thr) : (m == 2 ? is_nan : false);
+      const bool left = miss ? (nd.flags & 1) : (f <= nd.thr);
+      node = left ? (int)nd.left : (int)nd.right;
+    }
+    acc += lS[a.tree_leaf_off[t] - l0 + ~node];
+  }
+  red[w * 64 + lane] = acc;
+  __syncthreads();
+  if (w == 0 && row < a.n)
+    a.part[(size_t)chunk * a.n + row] = ((red[lane] + red[64 + lane]) + red[128 + lane]) + red[192 + lane];
+}
+
 __global__ void gbdt_reduce_kernel(const double* __restrict__ part, int n_chunks, int64_t n, double scale, double* out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -154,6 +229,44 @@ std::vector<T> parse_list(const std::string& s) {
     else out.push_back((T)strtoll(tok.c_str(), nullptr, 10));
   }
   return out;
+}
+
+// largest float not above x
+static float f32_floor(double x) {
+  float f = (float)x;
+  if ((double)f > x) f = nextafterf(f, -INFINITY);
+  return f;
+}
+
+static void build_compact(Forest* F, bool any_cat) {
+  F->compact = false;
+  if (any_cat || F->n_trees == 0 || F->n_features > 255) return;
+  for (int t = 0; t < F->n_trees; ++t) {
+    const int tn = F->tree_node_off[t + 1] - F->tree_node_off[t], tl = F->tree_leaf_off[t + 1] - F->tree_leaf_off[t];
+    if (tn > 127 || tl > 128 || tn > N8_CAP || tl > L8_CAP) return;
+  }
+  F->nodes8.resize(F->nodes.size());
+  for (size_t i = 0; i < F->nodes.size(); ++i) {
+    const Node& nd = F->nodes[i];
+    if (nd.dtype & 1) return;
+    if (nd.left > 127 || nd.left < -128 || nd.right > 127 || nd.right < -128 || nd.feat < 0 || nd.feat > 255) return;
+    Node8 c;
+    c.thr = f32_floor(nd.thr);
+    c.left = (int8_t)nd.left; c.right = (int8_t)nd.right; c.feat = (uint8_t)nd.feat;
+    c.flags = (uint8_t)(((nd.dtype >> 1) & 1) | (((nd.dtype >> 2) & 3) << 1));
+    F->nodes8[i] = c;
+  }
+  F->zero_thr32 = f32_floor(1e-35);
+  F->chunk8.clear();
+  F->chunk8.push_back(0);
+  int cn = 0, cl = 0, ct = 0;
+  for (int t = 0; t < F->n_trees; ++t) {
+    const int tn = F->tree_node_off[t + 1] - F->tree_node_off[t], tl = F->tree_leaf_off[t + 1] - F->tree_leaf_off[t];
+    if (ct > 0 && (cn + tn > N8_CAP || cl + tl > L8_CAP || ct >= T8_CAP)) { F->chunk8.push_back(t); cn = cl = ct = 0; }
+    cn += tn; cl += tl; ++ct;
+  }
+  F->chunk8.push_back(F->n_trees);
+  F->compact = true;
 }
 
 int parse_model(const std::string& text, Forest* F) {
@@ -247,6 +360,7 @@ int parse_model(const std::string& text, Forest* F) {
     cn += tn; cl += tl; ++ct;
   }
   F->chunk_tree_start.push_back(F->n_trees);
+  build_compact(F, any_cat);
   return RIHIP_OK;
 }
 
@@ -264,7 +378,7 @@ void destroy_forest(Forest* F) {
   if (!F) return;
   hipFree(F->d_nodes); hipFree(F->d_leaves); hipFree(F->d_tree_node_off); hipFree(F->d_tree_leaf_off); hipFree(F->d_tree_root);
   hipFree(F->d_chunk); hipFree(F->d_cat_b); hipFree(F->d_cat_w); hipFree(F->d_tree_cat_b_off); hipFree(F->d_tree_cat_w_off);
-  hipFree(F->d_part);
+  hipFree(F->d_part); hipFree(F->d_nodes8); hipFree(F->d_chunk8);
   delete F;
 }
 
@@ -284,6 +398,10 @@ extern "C" int rihip_gbdt_create_from_text(const char* text, int64_t len, void**
     if (!rc) rc = upload(F->tree_leaf_off, &F->d_tree_leaf_off);
     if (!rc) rc = upload(F->tree_root, &F->d_tree_root);
     if (!rc) rc = upload(F->chunk_tree_start, &F->d_chunk);
+    if (!rc && F->compact) {
+      rc = upload(F->nodes8, &F->d_nodes8);
+      if (!rc) rc = upload(F->chunk8, &F->d_chunk8);
+    }
     if (!rc && !F->cat_boundaries.empty()) {
       rc = upload(F->cat_boundaries, &F->d_cat_b);
       if (!rc) rc = upload(F->cat_words, &F->d_cat_w);
@@ -338,12 +456,32 @@ extern "C" int rihip_gbdt_predict(void* handle, const float* X, int64_t n, int l
   if (n == 0) return RIHIP_OK;
   hipStream_t st = (hipStream_t)stream;
   if (F->n_trees == 0) { RIHIP_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(double) * n, st)); return RIHIP_OK; }
-  const int n_chunks = (int)F->chunk_tree_start.size() - 1;
+  const bool compact = F->compact && F->d_nodes8 != nullptr;
+  const int n_chunks = compact ? (int)F->chunk8.size() - 1 : (int)F->chunk_tree_start.size() - 1;
   if (F->part_elems < (int64_t)n_chunks * n) {
     if (F->d_part) hipFree(F->d_part);
     F->d_part = nullptr; F->part_elems = 0;
     RIHIP_CHECK_HIP(hipMalloc((void**)&F->d_part, sizeof(double) * (size_t)n_chunks * n));
     F->part_elems = (int64_t)n_chunks * n;
+  }
+  if (compact) {
+    Pred8Args c;
+    c.nodes = F->d_nodes8; c.leaves = F->d_leaves; c.tree_node_off = F->d_tree_node_off; c.tree_leaf_off = F->d_tree_leaf_off;
+    c.tree_root = F->d_tree_root; c.chunk = F->d_chunk8; c.X = X; c.n = n; c.F = F->n_features; c.ldx = ldx;
+    c.zero_thr = F->zero_thr32; c.part = F->d_part;
+    const size_t lds = sizeof(Node8) * N8_CAP + sizeof(double) * (L8_CAP + 4 * 64) + sizeof(float) * 64 * (size_t)F->n_features;
+    static bool granted = false;
+    if (!granted) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gbdt_predict8_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(Node8) * N8_CAP + sizeof(double) * (L8_CAP + 4 * 64) + sizeof(float) * 64 * 255));
+      granted = true;
+    }
+    hipLaunchKernelGGL(gbdt_predict8_kernel, dim3((unsigned)((n + 63) / 64), n_chunks), dim3(256), lds, st, c);
+    RIHIP_CHECK_LAUNCH();
+    const double scale8 = F->average_output ? 1.0 / (double)F->n_trees : 1.0;
+    hipLaunchKernelGGL(gbdt_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, F->d_part, n_chunks, n, scale8, out);
+    RIHIP_CHECK_LAUNCH();
+    return RIHIP_OK;
   }
   PredArgs a;
   a.nodes = F->d_nodes; a.leaves = F->d_leaves; a.tree_node_off = F->d_tree_node_off; a.tree_leaf_off = F->d_tree_leaf_off;

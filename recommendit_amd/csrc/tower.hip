@@ -545,9 +545,11 @@ extern "C" int rihip_tower_forward(const float* table, int64_t n_rows, const int
   hipStream_t st = (hipStream_t)stream;
   a.W1p = nullptr; a.W2p = nullptr;
   {  // wave-per-32-rows kernel (tower2.hip): weights in LDS, activations in registers, no barrier in the row loop
-    static const char* ev = getenv("RIHIP_TOWER_FWD");
+    const char* ev = getenv("RIHIP_TOWER_FWD");  // 1: 64-row-tile kernel, 3: wave-per-32-rows kernel at any size (tests)
     const int which = ev ? atoi(ev) : 2;
-    if (which == 2 && aligned16(W2) && (reinterpret_cast<uintptr_t>(W1) & 7) == 0 &&
+    // it needs >= 8 row tiles of 32 per CU to fill the chip (one 147 KB weight fill per workgroup): below ~48k rows
+    // the 64-row-tile kernel with its 2 small workgroups per CU is faster
+    if (((which == 2 && B >= 49152) || which == 3) && aligned16(W2) && (reinterpret_cast<uintptr_t>(W1) & 7) == 0 &&
         rihip_launch_tower_fwd2(d, hidden, item, a, st)) {
       RIHIP_CHECK_LAUNCH();
       return RIHIP_OK;

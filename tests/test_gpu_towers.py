@@ -36,6 +36,17 @@ def t(x):
     return torch.from_numpy(np.asarray(x)).to(dev())
 
 
+@pytest.fixture(params=["auto", "rows32"])
+def fwd_kernel(request, monkeypatch):
+    """Both forward-kernel families on every shape: "auto" = the library's choice (64-row LDS tiles below ~48k rows),
+    "rows32" = the wave-per-32-rows kernel (tower2.hip) forced at any size."""
+    if request.param == "rows32":
+        monkeypatch.setenv("RIHIP_TOWER_FWD", "3")
+    else:
+        monkeypatch.delenv("RIHIP_TOWER_FWD", raising=False)
+    return request.param
+
+
 def test_library_targets_this_gpu():
     import ctypes
     from recommendit_amd import _lib
@@ -45,7 +56,7 @@ def test_library_targets_this_gpu():
 
 
 @pytest.mark.parametrize("tag", ["small", "ml1m", "d128"])
-def test_g1_tower_forward_golden(golden_dir, tag):
+def test_g1_tower_forward_golden(golden_dir, tag, fwd_kernel):
     g = np.load(golden_dir / "g1_tower_forward.npz")
     nu, ni, d, H, seed = (int(x) for x in g[f"{tag}_cfg"])
     m, sd = _model(nu, ni, d, H, seed)
@@ -62,7 +73,7 @@ def test_g1_tower_forward_golden(golden_dir, tag):
 @pytest.mark.parametrize("cfg", [(100, 200, 32, 64), (100, 200, 64, 128), (50, 60, 128, 128), (50, 60, 64, 64),
                                  (50, 60, 32, 128)])
 @pytest.mark.parametrize("B", [1, 63, 64, 65, 1000])
-def test_tower_forward_vs_oracle_ragged(cfg, B):
+def test_tower_forward_vs_oracle_ragged(cfg, B, fwd_kernel):
     nu, ni, d, H = cfg
     m, sd = _model(nu, ni, d, H, seed=77)
     m.eval()
@@ -112,7 +123,7 @@ def test_g2_bpr_grads_golden(golden_dir, tag):
 
 @pytest.mark.parametrize("cfg", [(100, 200, 32, 64, 200), (100, 200, 64, 128, 129), (50, 60, 128, 128, 70),
                                  (50, 60, 64, 64, 64), (50, 60, 32, 128, 5)])
-def test_backward_vs_oracle_with_dropout_mask(cfg):
+def test_backward_vs_oracle_with_dropout_mask(cfg, fwd_kernel):
     """train-mode dropout: the kernel's counter-based mask is reproduced bit-for-bit by the oracle."""
     nu, ni, d, H, B = cfg
     p_drop = 0.25
@@ -316,7 +327,7 @@ def test_g4_train50_golden_with_stock_adam(golden_dir):
         np.testing.assert_allclose(prm.detach().cpu().numpy(), g[f"final_{k}"], atol=2e-4, rtol=0, err_msg=k)
 
 
-def test_g5_g6_inference_and_reference_checkpoint(golden_dir, tmp_path):
+def test_g5_g6_inference_and_reference_checkpoint(golden_dir, tmp_path, fwd_kernel):
     from recommendit_amd import TwoTowerModel
     g = np.load(golden_dir / "g5_inference.npz")
     nu, ni, d, H, seed = (int(x) for x in g["cfg"])
