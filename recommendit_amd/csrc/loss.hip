@@ -57,6 +57,48 @@ __global__ __launch_bounds__(256) void bpr_pair_kernel(const float* __restrict__
   if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// float4 form for d in {32, 64, 128}: LPR = d/4 lanes per row, 64/LPR rows per wave side by side
+template <int LPR>
+__global__ __launch_bounds__(256) void bpr_pair_v4_kernel(const float* __restrict__ U, const float* __restrict__ P,
+                                                          const float* __restrict__ N, int64_t B, float inv_B,
+                                                          float* dU, float* dP, float* dN, double* part) {
+  constexpr int RPW = 64 / LPR, d = LPR * 4;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int sub = lane / LPR, c4 = lane % LPR;
+  double acc = 0.0;
+  for (int64_t b0 = ((int64_t)blockIdx.x * 4 + w) * RPW; b0 < B; b0 += (int64_t)gridDim.x * 4 * RPW) {
+    const int64_t b = b0 + sub;
+    const bool ok = b < B;
+    const int64_t bc = ok ? b : B - 1;
+    const f32x4 u = reinterpret_cast<const f32x4*>(U + bc * d)[c4];
+    const f32x4 p = reinterpret_cast<const f32x4*>(P + bc * d)[c4];
+    const f32x4 n = reinterpret_cast<const f32x4*>(N + bc * d)[c4];
+    float sp = (u.x * p.x + u.y * p.y) + (u.z * p.z + u.w * p.w);
+    float sn = (u.x * n.x + u.y * n.y) + (u.z * n.z + u.w * n.w);
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) {
+      sp += __shfl_xor(sp, o, 64);
+      sn += __shfl_xor(sn, o, 64);
+    }
+    const float delta = sp - sn;
+    const float e = expf(-fabsf(delta));
+    const float loss = fmaxf(-delta, 0.f) + log1pf(e);
+    const float sig_neg = (delta >= 0.f) ? e / (1.f + e) : 1.f / (1.f + e);  // sigmoid(-delta)
+    const float wgt = -sig_neg * inv_B;
+    if (ok) {
+      reinterpret_cast<f32x4*>(dU + b * d)[c4] = f32x4{wgt * (p.x - n.x), wgt * (p.y - n.y), wgt * (p.z - n.z), wgt * (p.w - n.w)};
+      reinterpret_cast<f32x4*>(dP + b * d)[c4] = f32x4{wgt * u.x, wgt * u.y, wgt * u.z, wgt * u.w};
+      reinterpret_cast<f32x4*>(dN + b * d)[c4] = f32x4{-wgt * u.x, -wgt * u.y, -wgt * u.z, -wgt * u.w};
+      if (c4 == 0) acc += (double)loss;
+    }
+  }
+  acc = wave_sum_d(acc);
+  __shared__ double sh[4];
+  if (lane == 0) sh[w] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
 // loss = scale * sum(part[0..n))  -- single wave, fixed order => deterministic
 __global__ void finalize_sum_kernel(const double* __restrict__ part, int n, double scale, float* out) {
   double s = 0.0;
@@ -526,8 +568,13 @@ extern "C" int rihip_bpr_pair_loss(const float* U, const float* P, const float* 
   hipStream_t st = (hipStream_t)stream;
   const int64_t nb = (B + 3) / 4;
   const int grid = (int)(nb < 1024 ? nb : 1024);
-  hipLaunchKernelGGL(bpr_pair_kernel, dim3(grid), dim3(256), 0, st, U, P, N, B, d, 1.f / (float)B, dU, dP, dN,
-                     workspace);
+  const bool al = ((reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(N) |
+                    reinterpret_cast<uintptr_t>(dU) | reinterpret_cast<uintptr_t>(dP) | reinterpret_cast<uintptr_t>(dN)) & 15) == 0;
+  const float inv_B = 1.f / (float)B;
+  if (al && d == 128) hipLaunchKernelGGL((bpr_pair_v4_kernel<32>), dim3(grid), dim3(256), 0, st, U, P, N, B, inv_B, dU, dP, dN, workspace);
+  else if (al && d == 64) hipLaunchKernelGGL((bpr_pair_v4_kernel<16>), dim3(grid), dim3(256), 0, st, U, P, N, B, inv_B, dU, dP, dN, workspace);
+  else if (al && d == 32) hipLaunchKernelGGL((bpr_pair_v4_kernel<8>), dim3(grid), dim3(256), 0, st, U, P, N, B, inv_B, dU, dP, dN, workspace);
+  else hipLaunchKernelGGL(bpr_pair_kernel, dim3(grid), dim3(256), 0, st, U, P, N, B, d, inv_B, dU, dP, dN, workspace);
   RIHIP_CHECK_LAUNCH();
   hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(64), 0, st, workspace, grid, 1.0 / (double)B, loss);
   RIHIP_CHECK_LAUNCH();

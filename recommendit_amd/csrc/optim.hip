@@ -209,6 +209,99 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ tabl
   }
 }
 
+// ---- float4 forms for d in {32, 64, 128}: LPR = d/4 lanes per row, 64/LPR rows (or blocks of sorted positions) per
+// wave side by side; per element the same operations in the same order as the scalar kernels above.
+template <int LPR>
+__global__ __launch_bounds__(256) void rows_partial_v4_kernel(const float* __restrict__ dX, const int* __restrict__ perm,
+                                                              const int64_t* __restrict__ sorted, int64_t B,
+                                                              float* __restrict__ P) {
+  constexpr int RPW = 64 / LPR, d = LPR * 4;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int sub = lane / LPR, c4 = lane % LPR;
+  const int64_t nblk = (B + RB - 1) / RB;
+  for (int64_t b = ((int64_t)blockIdx.x * 4 + w) * RPW + sub; b < nblk; b += (int64_t)gridDim.x * 4 * RPW) {
+    const int64_t p0 = b * RB, p1 = (p0 + RB < B) ? p0 + RB : B;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int64_t run = p0;
+    int64_t prev = sorted[p0];
+#pragma unroll 4
+    for (int64_t i = p0; i < p1; ++i) {
+      const int64_t k = sorted[i];
+      const f32x4 v = reinterpret_cast<const f32x4*>(dX + (size_t)perm[i] * d)[c4];
+      if (k != prev) {
+        reinterpret_cast<f32x4*>(P + (size_t)run * d)[c4] = acc;
+        run = i;
+        acc = v;
+        prev = k;
+      } else {
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+    reinterpret_cast<f32x4*>(P + (size_t)run * d)[c4] = acc;
+  }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void rows_combine_v4_kernel(const float* __restrict__ P,
+                                                              const int* __restrict__ seg_start,
+                                                              const int64_t* __restrict__ uniq,
+                                                              const int* __restrict__ n_unique, float* Gc,
+                                                              double* part) {
+  constexpr int RPW = 64 / LPR, d = LPR * 4;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int sub = lane / LPR, c4 = lane % LPR;
+  const int nu = *n_unique;
+  double acc = 0.0;
+  for (int u = (blockIdx.x * 4 + w) * RPW + sub; u < nu; u += gridDim.x * 4 * RPW) {
+    const int s0 = seg_start[u], s1 = seg_start[u + 1];
+    const bool pad = uniq[u] == 0;  // padding_idx row: gradient forced to zero (nn.Embedding semantics)
+    const int q0 = (s0 / RB + 1) * RB;
+    f32x4 s = reinterpret_cast<const f32x4*>(P + (size_t)s0 * d)[c4];
+#pragma unroll 4
+    for (int q = q0; q < s1; q += RB) {
+      const f32x4 v = reinterpret_cast<const f32x4*>(P + (size_t)q * d)[c4];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (pad) s = f32x4{0.f, 0.f, 0.f, 0.f};
+    reinterpret_cast<f32x4*>(Gc + (size_t)u * d)[c4] = s;
+    acc += ((double)s.x * (double)s.x + (double)s.y * (double)s.y) + ((double)s.z * (double)s.z + (double)s.w * (double)s.w);
+  }
+  acc = wave_sum_d(acc);
+  __shared__ double sh[4];
+  if (lane == 0) sh[w] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void adam_rows_v4_kernel(float* __restrict__ table, float* __restrict__ m,
+                                                           float* __restrict__ v, const int64_t* __restrict__ uniq,
+                                                           const float* __restrict__ Gc,
+                                                           const int* __restrict__ n_unique, const float* coef_dev,
+                                                           AdamHyper h, const float* hyper_dev) {
+  constexpr int RPW = 64 / LPR, d = LPR * 4;
+  if (hyper_dev) { h.lr_over_bc1 = hyper_dev[0]; h.sqrt_bc2 = hyper_dev[1]; }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int sub = lane / LPR, c4 = lane % LPR;
+  const int nu = *n_unique;
+  const float coef = coef_dev ? *coef_dev : 1.f;
+  for (int u = (blockIdx.x * 4 + w) * RPW + sub; u < nu; u += gridDim.x * 4 * RPW) {
+    const size_t row = (size_t)uniq[u] * d;
+    f32x4 pp = reinterpret_cast<f32x4*>(table + row)[c4], mm = reinterpret_cast<f32x4*>(m + row)[c4],
+          vv = reinterpret_cast<f32x4*>(v + row)[c4];
+    const f32x4 gg = reinterpret_cast<const f32x4*>(Gc + (size_t)u * d)[c4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float pk = pp[k], mk = mm[k], vk = vv[k];
+      adam_elem(pk, gg[k], mk, vk, coef, h);
+      pp[k] = pk; mm[k] = mk; vv[k] = vk;
+    }
+    reinterpret_cast<f32x4*>(table + row)[c4] = pp;
+    reinterpret_cast<f32x4*>(m + row)[c4] = mm;
+    reinterpret_cast<f32x4*>(v + row)[c4] = vv;
+  }
+}
+
 AdamHyper make_hyper(float lr, float b1, float b2, float eps, float wd, int64_t step) {
   AdamHyper h;
   const double bc1 = 1.0 - pow((double)b1, (double)step);
@@ -462,11 +555,21 @@ extern "C" int rihip_rows_reduce(const float* dX, int64_t B, int d, const int64_
   RIHIP_REQUIRE(rows_ws_layout(B, d, workspace, &ws) == RIHIP_OK, RIHIP_ERR_HIP, "rows_reduce: size query failed");
   const int64_t nblk = (B + RB - 1) / RB;
   const int g1 = (int)((nblk + 3) / 4 < 4096 ? (nblk + 3) / 4 : 4096);
-  hipLaunchKernelGGL(rows_partial_kernel, dim3(g1), dim3(256), 0, (hipStream_t)stream, dX, ws.perm, ws.keys_out, B, d,
-                     ws.P);
-  RIHIP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(rows_combine_kernel, dim3(ROWS_GRID), dim3(256), 0, (hipStream_t)stream, ws.P, ws.seg_start, uniq,
-                     ws.n_unique, d, Gc, part);
+  hipStream_t st = (hipStream_t)stream;
+  const bool al = ((reinterpret_cast<uintptr_t>(dX) | reinterpret_cast<uintptr_t>(ws.P) | reinterpret_cast<uintptr_t>(Gc)) & 15) == 0;
+  if (al && d == 128) {
+    hipLaunchKernelGGL((rows_partial_v4_kernel<32>), dim3(g1), dim3(256), 0, st, dX, ws.perm, ws.keys_out, B, ws.P);
+    hipLaunchKernelGGL((rows_combine_v4_kernel<32>), dim3(ROWS_GRID), dim3(256), 0, st, ws.P, ws.seg_start, uniq, ws.n_unique, Gc, part);
+  } else if (al && d == 64) {
+    hipLaunchKernelGGL((rows_partial_v4_kernel<16>), dim3(g1), dim3(256), 0, st, dX, ws.perm, ws.keys_out, B, ws.P);
+    hipLaunchKernelGGL((rows_combine_v4_kernel<16>), dim3(ROWS_GRID), dim3(256), 0, st, ws.P, ws.seg_start, uniq, ws.n_unique, Gc, part);
+  } else if (al && d == 32) {
+    hipLaunchKernelGGL((rows_partial_v4_kernel<8>), dim3(g1), dim3(256), 0, st, dX, ws.perm, ws.keys_out, B, ws.P);
+    hipLaunchKernelGGL((rows_combine_v4_kernel<8>), dim3(ROWS_GRID), dim3(256), 0, st, ws.P, ws.seg_start, uniq, ws.n_unique, Gc, part);
+  } else {
+    hipLaunchKernelGGL(rows_partial_kernel, dim3(g1), dim3(256), 0, st, dX, ws.perm, ws.keys_out, B, d, ws.P);
+    hipLaunchKernelGGL(rows_combine_kernel, dim3(ROWS_GRID), dim3(256), 0, st, ws.P, ws.seg_start, uniq, ws.n_unique, d, Gc, part);
+  }
   RIHIP_CHECK_LAUNCH();
   return RIHIP_OK;
 }
@@ -479,9 +582,14 @@ extern "C" int rihip_adam_rows(float* table, float* m, float* v, const int64_t* 
                 "adam_rows: bad arguments");
   RowsWs ws;
   RIHIP_REQUIRE(rows_ws_layout(B, d, workspace, &ws) == RIHIP_OK, RIHIP_ERR_HIP, "adam_rows: size query failed");
-  hipLaunchKernelGGL(adam_rows_kernel, dim3(ROWS_GRID), dim3(256), 0, (hipStream_t)stream, table, m, v, uniq, Gc,
-                     ws.n_unique, d, clip_coef, make_hyper(lr, beta1, beta2, eps, weight_decay, step >= 1 ? step : 1),
-                     hyper_dev);
+  const AdamHyper hy = make_hyper(lr, beta1, beta2, eps, weight_decay, step >= 1 ? step : 1);
+  hipStream_t st = (hipStream_t)stream;
+  const bool al = ((reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
+                    reinterpret_cast<uintptr_t>(Gc)) & 15) == 0;
+  if (al && d == 128) hipLaunchKernelGGL((adam_rows_v4_kernel<32>), dim3(ROWS_GRID), dim3(256), 0, st, table, m, v, uniq, Gc, ws.n_unique, clip_coef, hy, hyper_dev);
+  else if (al && d == 64) hipLaunchKernelGGL((adam_rows_v4_kernel<16>), dim3(ROWS_GRID), dim3(256), 0, st, table, m, v, uniq, Gc, ws.n_unique, clip_coef, hy, hyper_dev);
+  else if (al && d == 32) hipLaunchKernelGGL((adam_rows_v4_kernel<8>), dim3(ROWS_GRID), dim3(256), 0, st, table, m, v, uniq, Gc, ws.n_unique, clip_coef, hy, hyper_dev);
+  else hipLaunchKernelGGL(adam_rows_kernel, dim3(ROWS_GRID), dim3(256), 0, st, table, m, v, uniq, Gc, ws.n_unique, d, clip_coef, hy, hyper_dev);
   RIHIP_CHECK_LAUNCH();
   return RIHIP_OK;
 }
