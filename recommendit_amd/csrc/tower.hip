@@ -238,21 +238,6 @@ __global__ __launch_bounds__(256, 2) void tower_fwd_kernel(TowerFwdArgs a) {
 // -----------------------------------------------------------------------------------------
 // Backward
 // -----------------------------------------------------------------------------------------
-struct TowerBwdArgs {
-  const float* table;
-  int64_t n_rows;
-  const int64_t* ids;
-  const float* genres;
-  int64_t B;
-  const float *W1, *W2;
-  const float* gout;   // [B,D] dL/d out
-  const float* out;    // [B,D]
-  const float* denom;  // [B]
-  const float* hid;    // [B,H]
-  float scale;         // dropout 1/(1-p) (1 when not training)
-  float* dX;           // [B,D] per-sample embedding-row grads
-  float* slab;         // [grid][P] partial weight grads, P = H*K1 + H + D*H + D
-};
 
 template <int D, int H, bool ITEM>
 __global__ __launch_bounds__(256) void tower_bwd_kernel(TowerBwdArgs a) {
@@ -580,9 +565,10 @@ extern "C" int64_t rihip_tower_forward_workspace_floats(int d, int hidden, int i
 extern "C" int64_t rihip_tower_backward_workspace_floats(int64_t B, int d, int hidden, int item) {
   const int K1 = d + (item ? 18 : 0);
   const int64_t P = (int64_t)hidden * K1 + hidden + (int64_t)d * hidden + d;
-  const int64_t ntiles = (B + TM - 1) / TM;
-  const int64_t grid = ntiles < RIHIP_NCU ? ntiles : RIHIP_NCU;
-  return ((grid > 0 ? grid : 1) + SLAB_GROUPS) * P;
+  const int64_t nt32 = (B + 31) / 32;
+  const int64_t grid = nt32 < RIHIP_NCU ? nt32 : RIHIP_NCU;   // most slabs any backward variant writes
+  // slabs + level-1 partials + (two-kernel backward) gy [B,d] and dPre [B,hidden]
+  return ((grid > 0 ? grid : 1) + SLAB_GROUPS) * P + B * (int64_t)(d + hidden);
 }
 
 extern "C" int rihip_tower_backward(const float* table, int64_t n_rows, const int64_t* ids, const float* genres,
@@ -606,14 +592,27 @@ extern "C" int rihip_tower_backward(const float* table, int64_t n_rows, const in
   const int grid = (int)(ntiles < RIHIP_NCU ? ntiles : RIHIP_NCU);
   const bool item = genres != nullptr;
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH_DH(launch_bwd, item, a, grid, st)
-  RIHIP_CHECK_LAUNCH();
   const int K1 = d + (item ? 18 : 0);
   const int P = hidden * K1 + hidden + d * hidden + d;
-  const int G = grid < SLAB_GROUPS ? grid : SLAB_GROUPS;
-  float* part = workspace + (size_t)grid * P;
-  if (grid > SLAB_GROUPS)
-    hipLaunchKernelGGL(slab_reduce1_kernel, dim3((P + 255) / 256, G), dim3(256), 0, st, workspace, grid, P, G, part);
+  const int64_t nt32 = (B + 31) / 32;
+  const int grid_ws = (int)(nt32 < RIHIP_NCU ? nt32 : RIHIP_NCU);   // slab slots in the workspace layout
+  float* part = workspace + (size_t)(grid_ws > 0 ? grid_ws : 1) * P;
+  float* act = part + (size_t)SLAB_GROUPS * P;
+  int nslab = 0;
+  {  // two-kernel backward (tower2.hip) for chip-filling batches; 1 = the fused 64-row-tile kernel
+    const char* ev = getenv("RIHIP_TOWER_BWD");
+    const int which = ev ? atoi(ev) : 2;
+    if (((which == 2 && B >= 49152) || which == 3) && aligned16(W2) && aligned16(dX))
+      nslab = rihip_launch_tower_bwd2(d, hidden, item, a, act, st);
+  }
+  if (nslab == 0) {
+    DISPATCH_DH(launch_bwd, item, a, grid, st)
+    nslab = grid;
+  }
+  RIHIP_CHECK_LAUNCH();
+  const int G = nslab < SLAB_GROUPS ? nslab : SLAB_GROUPS;
+  if (nslab > SLAB_GROUPS)
+    hipLaunchKernelGGL(slab_reduce1_kernel, dim3((P + 255) / 256, G), dim3(256), 0, st, workspace, nslab, P, G, part);
   else
     part = workspace;  // at most SLAB_GROUPS slabs: level 1 would be a copy (same summation order either way)
   hipLaunchKernelGGL(slab_reduce2_kernel, dim3((P + 255) / 256), dim3(256), 0, st, part, G, P, hidden, K1, d, dW1, db1,

@@ -22,5 +22,26 @@ struct TowerFwdArgs {
   int* err_flag;    // set to 1 on out-of-range id (nullable)
 };
 
+struct TowerBwdArgs {
+  const float* table;
+  int64_t n_rows;
+  const int64_t* ids;
+  const float* genres;
+  int64_t B;
+  const float *W1, *W2;
+  const float* gout;   // [B,D] dL/d out
+  const float* out;    // [B,D]
+  const float* denom;  // [B]
+  const float* hid;    // [B,H]
+  float scale;         // dropout 1/(1-p) (1 when not training)
+  float* dX;           // [B,D] per-sample embedding-row grads
+  float* slab;         // [grid][P] partial weight grads, P = H*K1 + H + D*H + D
+};
+
+// two-kernel backward (tower2.hip): data-gradient kernel (wave per 32 rows, weights in LDS) that also writes gy [B,D]
+// and dPre [B,H] to `act`, then the weight-gradient kernel (LDS-tiled split-K over the batch) that fills the slabs.
+// Returns the number of slabs written (0: no instantiation for this (d, hidden)).
+int rihip_launch_tower_bwd2(int d, int hidden, bool item, const TowerBwdArgs& a, float* act, hipStream_t st);
+
 // wave-per-32-rows forward (tower2.hip); returns false when the (d, hidden) pair has no instantiation
 bool rihip_launch_tower_fwd2(int d, int hidden, bool item, const TowerFwdArgs& a, hipStream_t st);

@@ -38,12 +38,14 @@ def t(x):
 
 @pytest.fixture(params=["auto", "rows32"])
 def fwd_kernel(request, monkeypatch):
-    """Both forward-kernel families on every shape: "auto" = the library's choice (64-row LDS tiles below ~48k rows),
-    "rows32" = the wave-per-32-rows kernel (tower2.hip) forced at any size."""
+    """Both tower-kernel families on every shape: "auto" = the library's choice (64-row LDS tiles below ~48k rows),
+    "rows32" = the wave-per-32-rows forward and the two-kernel backward (tower2.hip) forced at any size."""
     if request.param == "rows32":
         monkeypatch.setenv("RIHIP_TOWER_FWD", "3")
+        monkeypatch.setenv("RIHIP_TOWER_BWD", "3")   # two-kernel backward (d = hidden = 128), any size
     else:
         monkeypatch.delenv("RIHIP_TOWER_FWD", raising=False)
+        monkeypatch.delenv("RIHIP_TOWER_BWD", raising=False)
     return request.param
 
 
@@ -102,7 +104,7 @@ def test_tower_forward_bitwise_reproducible_and_cpu_inputs():
 
 
 @pytest.mark.parametrize("tag", ["small", "mid"])
-def test_g2_bpr_grads_golden(golden_dir, tag):
+def test_g2_bpr_grads_golden(golden_dir, tag, fwd_kernel):
     g = np.load(golden_dir / "g2_bpr_grads.npz")
     nu, ni, d, H, seed, B = (int(x) for x in g[f"{tag}_cfg"])
     m, sd = _model(nu, ni, d, H, seed)
