@@ -292,6 +292,15 @@ __global__ __launch_bounds__(512, 2) void tower_bwd_data_kernel(TowerBwdArgs a, 
     const int64_t grow = row_base + r31;
     const bool ok = grow < a.B;
     const int64_t gr = ok ? grow : a.B - 1;  // clamped: every load unconditional
+    // the saved hidden activations of this lane's row are requested first: they are only needed after the first GEMM
+    f32x4 hv[HT * 4];
+    {
+      const float* hp = a.hid + gr * H + 4 * hh;
+#pragma unroll
+      for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hv[ht * 4 + q] = *reinterpret_cast<const f32x4*>(hp + ht * 32 + 8 * q);
+    }
     // ---- gy = (gout - out * <gout, out>) / denom   (lane (row, hh) holds its half of the row's k-blocks)
     f32x4 gy[KBD];
     {
@@ -336,17 +345,15 @@ __global__ __launch_bounds__(512, 2) void tower_bwd_data_kernel(TowerBwdArgs a, 
     }
     // ---- dPre (register r of tile ht <-> hidden unit ht*32 + acc_row(r); 4 consecutive units per float4)
     {
-      const float* hp = a.hid + gr * H + 4 * hh;
       float* pp = dpre_out + gr * H + 4 * hh;
 #pragma unroll
       for (int ht = 0; ht < HT; ++ht)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const f32x4 hv = *reinterpret_cast<const f32x4*>(hp + ht * 32 + 8 * q);
           f32x4 v;
 #pragma unroll
           for (int s2 = 0; s2 < 4; ++s2) {
-            v[s2] = (hv[s2] > 0.f && ok) ? hacc[ht][4 * q + s2] * a.scale : 0.f;
+            v[s2] = (hv[ht * 4 + q][s2] > 0.f && ok) ? hacc[ht][4 * q + s2] * a.scale : 0.f;
             hacc[ht][4 * q + s2] = v[s2];
           }
           if (ok) *reinterpret_cast<f32x4*>(pp + ht * 32 + 8 * q) = v;
@@ -496,7 +503,7 @@ __global__ __launch_bounds__(512, 2) void tower_wgrad_kernel(TowerBwdArgs a, con
     const float* Xs = Ps + TROWS * H;
     if (w < 4) {
       // dW2[d][hid] tiles (d-tile w, hidden tiles 0..3): A = gy columns, B = hid columns; k = row
-#pragma unroll 4
+#pragma unroll 8
       for (int s = 0; s < TROWS / 2; ++s) {
         const int row = 2 * s + hh;
         const float av = Gs[row * D + w * 32 + r31];
@@ -512,7 +519,7 @@ __global__ __launch_bounds__(512, 2) void tower_wgrad_kernel(TowerBwdArgs a, con
       colsum += cs;
     } else {
       // dW1[hid][k] tiles (hidden tile w-4, x tiles 0..NX-1): A = dPre columns, B = x columns
-#pragma unroll 4
+#pragma unroll 8
       for (int s = 0; s < TROWS / 2; ++s) {
         const int row = 2 * s + hh;
         const float av = Ps[row * H + (w - 4) * 32 + r31];
