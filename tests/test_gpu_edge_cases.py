@@ -88,3 +88,62 @@ def test_status_codes_not_aborts():
     with pytest.raises(RuntimeError, match="no HIP kernel instantiation|unsupported"):
         from recommendit_amd import TwoTowerModel
         TwoTowerModel(5, 5, embed_dim=48, hidden_dim=64).user_tower(torch.tensor([1]))
+
+
+def test_multi_tensor_launches_equal_single_tensor_calls():
+    """rihip_sumsq_multi / rihip_adam_dense_multi are the same arithmetic as three single-tensor calls, bit for bit,
+    and the zero_grad mask clears exactly the flagged gradients."""
+    from recommendit_amd import _lib as L
+    lib, dev, st = L.lib(), L.device(), L.stream_ptr()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    sizes = [4099, 640, 12800]
+    P = [torch.randn(n, generator=g).to(dev) for n in sizes]
+    G = [torch.randn(n, generator=g).to(dev) * 1e-2 for n in sizes]
+    M = [torch.rand(n, generator=g).to(dev) * 1e-3 for n in sizes]
+    V = [torch.rand(n, generator=g).to(dev) * 1e-5 for n in sizes]
+    npart = lib.rihip_sumsq_nparts()
+    part1 = torch.zeros(3 * npart, dtype=torch.float64, device=dev)
+    part2 = torch.zeros_like(part1)
+    for t in range(3):
+        L.check(lib.rihip_sumsq(G[t].data_ptr(), sizes[t], part1.data_ptr() + 8 * t * npart, st), "sumsq")
+    PA, NA = ctypes.c_void_p * 3, ctypes.c_int64 * 3
+    L.check(lib.rihip_sumsq_multi(3, PA(*[x.data_ptr() for x in G]), NA(*sizes), part2.data_ptr(), st), "sumsq_multi")
+    assert torch.equal(part1, part2)
+    coef = torch.full((1,), 0.7, dtype=torch.float32, device=dev)
+    P1, M1, V1 = [x.clone() for x in P], [x.clone() for x in M], [x.clone() for x in V]
+    for t in range(3):
+        L.check(lib.rihip_adam_dense(P1[t].data_ptr(), G[t].data_ptr(), M1[t].data_ptr(), V1[t].data_ptr(), sizes[t],
+                                     1e-3, 0.9, 0.999, 1e-8, 1e-5, 7, coef.data_ptr(), None, st), "adam_dense")
+    G2 = [x.clone() for x in G]
+    L.check(lib.rihip_adam_dense_multi(3, PA(*[x.data_ptr() for x in P]), PA(*[x.data_ptr() for x in G2]),
+                                       PA(*[x.data_ptr() for x in M]), PA(*[x.data_ptr() for x in V]), NA(*sizes), 0b101,
+                                       1e-3, 0.9, 0.999, 1e-8, 1e-5, 7, coef.data_ptr(), None, st), "adam_dense_multi")
+    for t in range(3):
+        assert torch.equal(P[t], P1[t]) and torch.equal(M[t], M1[t]) and torch.equal(V[t], V1[t])
+    assert float(G2[0].abs().max()) == 0.0 and float(G2[2].abs().max()) == 0.0 and torch.equal(G2[1], G[1])
+
+
+def test_rows_group_key_bits_hint_is_equivalent():
+    """Sorting only the significant id bits (n_rows hint) groups exactly like the full 64-bit sort."""
+    from recommendit_amd import _lib as L
+    lib, dev, st = L.lib(), L.device(), L.stream_ptr()
+    B, d, n_rows = 5000, 32, 1000
+    g = torch.Generator(device="cpu").manual_seed(9)
+    ids = torch.randint(0, n_rows, (B,), generator=g).to(dev)
+    dX = torch.randn(B, d, generator=g).to(dev)
+    outs = []
+    for hint in (0, n_rows, 1 << 40):
+        ws = torch.empty(lib.rihip_rows_workspace_bytes(B, d), dtype=torch.uint8, device=dev)
+        uniq = torch.empty(B, dtype=torch.int64, device=dev)
+        Gc = torch.zeros(B, d, dtype=torch.float32, device=dev)
+        part = torch.zeros(lib.rihip_rows_nparts(), dtype=torch.float64, device=dev)
+        L.check(lib.rihip_rows_group(ids.data_ptr(), B, d, hint, uniq.data_ptr(), ws.data_ptr(), ws.numel(), st), "group")
+        L.check(lib.rihip_rows_reduce(dX.data_ptr(), B, d, uniq.data_ptr(), ws.data_ptr(), Gc.data_ptr(), part.data_ptr(),
+                                      st), "reduce")
+        nu = int(torch.unique(ids).numel())
+        outs.append((uniq[:nu].clone(), Gc[:nu].clone(), part.clone()))
+    for u, gc, pt in outs[1:]:
+        assert torch.equal(u, outs[0][0]) and torch.equal(gc, outs[0][1]) and torch.equal(pt, outs[0][2])
+    ref = torch.zeros(n_rows, d, device=dev).index_add_(0, ids, dX)
+    np.testing.assert_allclose(outs[0][1].cpu().numpy(), ref[outs[0][0]].cpu().numpy() * (outs[0][0] != 0).float()[:, None].cpu().numpy(),
+                               atol=2e-5, rtol=1e-5)
