@@ -445,11 +445,13 @@ __global__ __launch_bounds__(256, 3) void scan_bf16_kernel(ScanArgs a) {
 template <int D>
 __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ X, const float* __restrict__ Q,
                                                      uint64_t* cand, int64_t cap, const int* __restrict__ count,
-                                                     float* qnorm, int64_t N) {
+                                                     float* qnorm, int64_t N, const float* __restrict__ kth_approx,
+                                                     float eps_scale) {
   constexpr int PER = D / 16;  // floats per lane
   const int64_t q = blockIdx.x;
   const int tid = threadIdx.x, l16 = tid & 15, grp = tid >> 4;
   float qv[PER];
+  float cut;
 #pragma unroll
   for (int j = 0; j < PER; ++j) qv[j] = Q[q * D + l16 * PER + j];
   {
@@ -459,6 +461,10 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ X
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (tid == 0) qnorm[q] = sqrtf(s);
+    // At least k candidates have an approximate score >= kth_approx[q], hence exact scores >= kth_approx - eps, so the
+    // exact k-th score T* >= kth_approx - eps; a candidate whose approximate score is below kth_approx - 2 eps has an
+    // exact score < kth_approx - eps <= T*: it cannot be in the top-k and its row is not fetched (key zeroed).
+    cut = kth_approx ? kth_approx[q] - 2.f * eps_scale * sqrtf(s) - 1e-6f : -INFINITY;
   }
   const int cnt = count[q];
   const int64_t n = cnt <= cap ? cnt : 0;  // overflowed list: the query is re-done exactly anyway
@@ -467,6 +473,10 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ X
     const uint64_t key = keys[i];
     const uint32_t row = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull);
     if ((int64_t)row >= N) continue;
+    if (ord2f((uint32_t)(key >> 32)) < cut) {
+      if (l16 == 0) keys[i] = 0ull;
+      continue;
+    }
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < PER; ++j) s = fmaf(qv[j], X[(size_t)row * D + l16 * PER + j], s);
@@ -832,7 +842,7 @@ struct IpIndex {
   // scratch (grown on demand, owned by the handle)
   DevBuf<uint64_t> cand, scand, fcand;
   DevBuf<int> count, fail_flags, fail_list, n_fail, fcount;
-  DevBuf<float> thr, fQ;
+  DevBuf<float> thr, thr2, fQ;
   DevBuf<uint32_t> probe_bits;
   DevBuf<int> blk_tiles, blk_ntiles;
   int* h_nfail = nullptr;  // pinned
@@ -1044,9 +1054,18 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
   RCCHK(run_scan(sa, two_prec ? (h->N + TRB - 1) / TRB : n_tiles));
   if (two_prec) {  // exact f32 re-score of the survivors (keys rewritten in place)
     RCCHK(h->qnorm.reserve(nq));
-    if (d == 32) hipLaunchKernelGGL((rerank_kernel<32>), dim3((unsigned)nq), dim3(256), 0, st, h->X, Q, h->cand.p, cap, h->count.p, h->qnorm.p, h->N);
-    else if (d == 64) hipLaunchKernelGGL((rerank_kernel<64>), dim3((unsigned)nq), dim3(256), 0, st, h->X, Q, h->cand.p, cap, h->count.p, h->qnorm.p, h->N);
-    else hipLaunchKernelGGL((rerank_kernel<128>), dim3((unsigned)nq), dim3(256), 0, st, h->X, Q, h->cand.p, cap, h->count.p, h->qnorm.p, h->N);
+    RCCHK(h->thr2.reserve(nq));
+    {  // k-th largest APPROXIMATE score per query (a lower bound of it: the select stops early): rerank_kernel uses it
+       // to skip survivors that provably cannot reach the top-k -- about half of them
+      FinArgs f2 = fa;
+      f2.cand = h->cand.p; f2.cap = cap; f2.mode = 1; f2.rank = k; f2.thr_out = h->thr2.p; f2.fail_flags = nullptr;
+      f2.thr_chk = nullptr; f2.qnorm = nullptr; f2.ivf_thr = nullptr; f2.need_min = 0;
+      hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3(256), 0, st, f2);
+    }
+    const float eps_sc = (float)((1.0 / 256.0 + 1.0 / 262144.0) * (double)h->max_norm * 1.001);
+    if (d == 32) hipLaunchKernelGGL((rerank_kernel<32>), dim3((unsigned)nq), dim3(256), 0, st, h->X, Q, h->cand.p, cap, h->count.p, h->qnorm.p, h->N, h->thr2.p, eps_sc);
+    else if (d == 64) hipLaunchKernelGGL((rerank_kernel<64>), dim3((unsigned)nq), dim3(256), 0, st, h->X, Q, h->cand.p, cap, h->count.p, h->qnorm.p, h->N, h->thr2.p, eps_sc);
+    else hipLaunchKernelGGL((rerank_kernel<128>), dim3((unsigned)nq), dim3(256), 0, st, h->X, Q, h->cand.p, cap, h->count.p, h->qnorm.p, h->N, h->thr2.p, eps_sc);
     fa.thr_chk = h->thr.p; fa.qnorm = h->qnorm.p;
     fa.eps_scale = (float)((1.0 / 256.0 + 1.0 / 262144.0) * (double)h->max_norm * 1.001);
   }
@@ -1102,7 +1121,7 @@ extern "C" int rihip_ip_index_destroy(void* handle) {
   if (!h) return RIHIP_OK;
   free_index_arrays(h);
   h->cand.release(); h->scand.release(); h->fcand.release(); h->count.release(); h->fail_flags.release();
-  h->fail_list.release(); h->n_fail.release(); h->fcount.release(); h->thr.release(); h->fQ.release();
+  h->fail_list.release(); h->n_fail.release(); h->fcount.release(); h->thr.release(); h->thr2.release(); h->fQ.release();
   h->probe_bits.release(); h->blk_tiles.release(); h->blk_ntiles.release(); h->qnorm.release();
   if (h->h_nfail) hipHostFree(h->h_nfail);
   delete h;
