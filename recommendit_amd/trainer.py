@@ -115,6 +115,7 @@ class HipBPRTrainer:
         self.use_graph = bool(use_graph)
         self._graph = None
         self._dI_work = None
+        self._side_stream = torch.cuda.Stream(device=self.dev)
         self._eager_steps = 0  # bench hook: list collecting (start, end) events around every sweep launch
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
@@ -317,10 +318,17 @@ class HipBPRTrainer:
         o1 = self.np_mlp
         o2 = o1 + self.np_rows
         if self.table_opt == "sparse":
-            self.uopt.group_reduce(user_ids, self.dXu, pp + 8 * o1, st)
+            # the two tables' group+reduce chains (~10 small dependent kernels each) are independent until the clip
+            # coefficient: the user chain runs on a side stream beside the item chain
+            cur = torch.cuda.current_stream(self.dev)
+            side = self._side_stream
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                self.uopt.group_reduce(user_ids, self.dXu, pp + 8 * o1, side.cuda_stream)
             if w_i is not None:
                 w_i.wait(); w_x.wait()
             self.iopt.group_reduce(iid, dXi, pp + 8 * o2, st)
+            cur.wait_stream(side)
         else:
             # dense tables (ML-1M scale): the table gradients were zeroed by the previous step's Adam launch
             self.uopt.scatter(user_ids, self.dXu, st, zero=False)
