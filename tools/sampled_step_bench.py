@@ -10,7 +10,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 nu, ni = 2_000_000, 1_000_000
 dev = torch.device("cuda")
 m = TwoTowerModel(nu, ni, 128, 128, dropout=0.1); m.train()
-tr = HipBPRTrainer(m, B, loss_mode="sampled", table_opt="sparse")
+USE_GRAPH = len(sys.argv) > 2 and sys.argv[2] == "graph"
+tr = HipBPRTrainer(m, B, loss_mode="sampled", table_opt="sparse", use_graph=USE_GRAPH)
 g = torch.Generator(device=dev); g.manual_seed(0)
 u = torch.randint(1, nu + 1, (B,), device=dev, generator=g)
 it = torch.randint(1, ni + 1, (2 * B,), device=dev, generator=g)
@@ -23,4 +24,4 @@ e0.record()
 for _ in range(20):
     tr.step(u, it, gen)
 e1.record(); torch.cuda.synchronize()
-print(f"B={B}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us/step")
+print(f"B={B} graph={USE_GRAPH}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us/step")
