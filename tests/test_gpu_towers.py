@@ -192,6 +192,20 @@ def test_inbatch_vs_oracle_ragged_and_reproducible(B, d, prec):
     np.testing.assert_allclose(dI1.cpu().numpy(), dIo, atol=3e-9, rtol=3e-4)
 
 
+@pytest.mark.parametrize("B,d", [(40, 32), (300, 64), (257, 128)])
+def test_inbatch_bf16x6_two_sweep_form_vs_oracle(B, d):
+    """precision=2 without the stored G: user-mode AND item-mode sweeps of loss_x6.hip (the form used when G does not
+    fit in HBM), at the f32 tolerances."""
+    from recommendit_amd.two_tower import inbatch_loss_and_grads
+    rng = np.random.RandomState(B + 5)
+    U, I = fx.unit_rows(rng, B, d), fx.unit_rows(rng, B, d)
+    loss, dU, dI = inbatch_loss_and_grads(t(U), t(I), precision=2, store_g=False)
+    lo, dUo, dIo = O.in_batch_bpr_loss(U, I)
+    assert abs(loss.item() - float(lo)) < 3e-6
+    np.testing.assert_allclose(dU.cpu().numpy(), dUo, atol=3e-9, rtol=3e-4)
+    np.testing.assert_allclose(dI.cpu().numpy(), dIo, atol=3e-9, rtol=3e-4)
+
+
 @pytest.mark.parametrize("B,d", [(33, 32), (257, 64), (500, 128)])
 def test_inbatch_stored_g_equals_recompute_form(B, d):
     """The stored-G form (user pass writes G, item pass = G^T.U) and the two-sweep form give the same dU/r bit for
