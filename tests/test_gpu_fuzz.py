@@ -55,3 +55,30 @@ def test_inbatch_random_shapes_vs_oracle():
         d = (32, 64, 128)[i % 3]
         prec = (0, 2)[(i // 3) % 2]
         _run(Bl, G, off, d, prec, store_g=(i % 4 != 3))
+
+
+def test_retrieval_random_shapes_exact():
+    """Two-precision search (sample threshold -> bf16 filter -> provable survivor cut -> exact re-score) against a
+    plain fp32 top-k on the device, over corpus sizes around the brute-force / sampled-path switch, with clustered
+    scores (many near-ties) and duplicated rows."""
+    from recommendit_amd import FAISSIndex
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(77)
+    for case, (N, d, nq, k) in enumerate([(70000, 32, 33, 10), (131072, 64, 257, 500), (300000, 128, 64, 100),
+                                          (90001, 64, 5, 1), (262144, 32, 100, 500)]):
+        X = torch.randn(N, d, generator=g)
+        if case % 2 == 1:   # clustered: low-rank structure + small noise -> dense near-ties around the k-th score
+            X = torch.randn(N, 4, generator=g) @ torch.randn(4, d, generator=g) + 0.01 * X
+        X[N // 2:N // 2 + 50] = X[:50]            # exact duplicates
+        X = torch.nn.functional.normalize(X, dim=1).contiguous()
+        Q = torch.nn.functional.normalize(torch.randn(nq, d, generator=g), dim=1).contiguous()
+        idx = FAISSIndex(embed_dim=d, exact=True)
+        idx.build_from_device(X.to(dev), np.arange(N))
+        sc, rows = idx.batch_search_device(Q.to(dev), k=k, normalized=True)
+        ref = (Q.to(dev) @ X.to(dev).T)
+        rs, _ = torch.topk(ref, k, dim=1)
+        # scores must match the exact top-k scores (rows may differ only among exactly tied scores)
+        np.testing.assert_allclose(sc.cpu().numpy(), rs.cpu().numpy(), atol=2e-6, rtol=0, err_msg=str((N, d, nq, k)))
+        got = torch.gather(ref, 1, rows.clamp_min(0))
+        np.testing.assert_allclose(got.cpu().numpy(), sc.cpu().numpy(), atol=2e-6, rtol=0)
+        assert all(len(set(r.tolist())) == k for r in rows.cpu())
