@@ -59,6 +59,7 @@ def zipf_ids(n, n_items, a, gen, device):
 
 
 def make_batches(n, B, n_users_local, n_items, device, seed, sampled):
+    n = min(n, 64)   # distinct synthetic batches kept in HBM (callers index modulo len): bounds memory for large --steps
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
     out = []
@@ -281,7 +282,7 @@ def main():
         tr = HipBPRTrainer(model, Bs, loss_mode="sampled", table_opt="sparse", seed=rank)
         batches = make_batches(W + K, Bs, n_users_local, args.items, dev, seed=9 + rank, sampled=True)
         for i in range(W):
-            tr.step(*batches[i])
+            tr.step(*batches[i % len(batches)])
         dts = timed(lambda i: tr.step(*batches[(W + i) % len(batches)]), K, world)
         sp = Bs * world * K / dts
         # HBM roofline of the sparse formulation: 9 384 B/pair at d=128; MFMA: 617 472 FLOP/pair
