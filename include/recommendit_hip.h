@@ -173,14 +173,26 @@ int rihip_adam_rows(float* table, float* m, float* v, const int64_t* uniq, const
  * search: Q device [nq,d]; out_scores f32[nq,k] descending, -inf padded; out_rows i64[nq,k]
  * row numbers in insertion order, -1 padded (faiss convention kept by faiss_index.py:148-152).
  * Exact for a flat index (ties -> lowest row); synchronises the stream once per 4096 queries
- * (exactness check).  k <= rihip_ip_index_max_k().  d in {32,64,128}. */
+ * (exactness check).  k <= rihip_ip_index_max_k() (16384).  d in {32,64,128}.  nlist <= 2048.
+ * IVF (faiss_index.py:68-74): train_ivf = k-means (Lloyd, IP assignment, mean update, empty lists keep their
+ * centroid) from seeded rows, then list-contiguous layout; train_ivf_from = the same from caller-supplied
+ * initial centroids (host [nlist,d]; n_iter = 0 partitions by them as they are); set_ivf injects centroids AND
+ * the list of every row (host int32 [N]) -- what a FAISS IndexIVFFlat file holds; get_ivf reads both back
+ * (host, either may be NULL); reconstruct returns the stored vectors in insertion order (host [N,d]);
+ * assign = list of each of n device rows under the index's centroids (device int32 [n]). */
 int rihip_ip_index_create(int d, void** handle);
 int rihip_ip_index_destroy(void* handle);
 int rihip_ip_index_set_vectors(void* handle, const float* X, int64_t N, int x_on_device, void* stream);
 int64_t rihip_ip_index_ntotal(void* handle);
 int rihip_ip_index_is_ivf(void* handle);
+int rihip_ip_index_nlist(void* handle);
 int rihip_ip_index_max_k(void);
 int rihip_ip_index_train_ivf(void* handle, int nlist, int n_iter, uint64_t seed, void* stream);
+int rihip_ip_index_train_ivf_from(void* handle, int nlist, int n_iter, const float* init_centroids, void* stream);
+int rihip_ip_index_set_ivf(void* handle, int nlist, const float* centroids, const int32_t* assign, void* stream);
+int rihip_ip_index_get_ivf(void* handle, float* centroids, int32_t* assign);   /* synchronous */
+int rihip_ip_index_reconstruct(void* handle, float* out);                       /* synchronous */
+int rihip_ip_index_assign(void* handle, const float* X, int64_t n, int32_t* assign, void* stream);
 int rihip_ip_index_set_nprobe(void* handle, int nprobe);
 /* flat indexes with N > 65536: 1 (default) = bf16-MFMA filter with a rigorous error bound + exact f32 re-score of
  * the survivors (results identical to the all-f32 search, proven per query, exact fallback otherwise); 0 = all-f32 */

@@ -51,34 +51,45 @@ def ivf_assign(X: np.ndarray, centroids: np.ndarray) -> np.ndarray:
     return np.argmax(X.astype(np.float64) @ centroids.astype(np.float64).T, axis=1).astype(np.int64)
 
 
-def ivf_search(Q, X, centroids, assign, nprobe: int, k: int):
-    """IVF-IP search given centroids + assignment: coarse top-nprobe lists by IP,
-    exact scan of those lists, top-k desc; -1 / -inf padding when fewer than k
-    (faiss convention kept by faiss_index.py:148-152)."""
+def ivf_search(Q, X, centroids, assign, nprobe: int, k: int, return_probe: bool = False):
+    """IVF-IP search given centroids + assignment: coarse top-nprobe lists by IP (ties -> lowest list id),
+    exact scan of those lists, top-k desc (ties -> lowest row); -1 / -inf padding when fewer than k
+    (faiss convention kept by faiss_index.py:148-152).  Scores in float64, rounded to float32.
+    return_probe: also return (probe lists i64[nq,nprobe], coarse scores f64[nq,nlist])."""
     nq = Q.shape[0]
     k = min(k, X.shape[0])
+    assign = np.asarray(assign)
+    nlist = centroids.shape[0]
     coarse = Q.astype(np.float64) @ centroids.astype(np.float64).T
     probe = np.argsort(-coarse, axis=1, kind="stable")[:, :nprobe]
+    order = np.argsort(assign, kind="stable")                       # rows grouped by list, ascending inside
+    starts = np.searchsorted(assign[order], np.arange(nlist + 1))
     out_s = np.full((nq, k), -np.inf, dtype=F32)
     out_i = np.full((nq, k), -1, dtype=np.int64)
     for q in range(nq):
-        rows = np.nonzero(np.isin(assign, probe[q]))[0]
+        rows = np.concatenate([order[starts[c]:starts[c + 1]] for c in probe[q]])
         if rows.size == 0:
             continue
-        s = Q[q].astype(np.float64) @ X[rows].astype(np.float64).T
+        s = X[rows].astype(np.float64) @ Q[q].astype(np.float64)
         o = np.lexsort((rows, -s))[:k]
         out_s[q, : o.size] = s[o].astype(F32)
         out_i[q, : o.size] = rows[o]
+    if return_probe:
+        return out_s, out_i, probe, coarse
     return out_s, out_i
 
 
-def kmeans_ip(X: np.ndarray, n_lists: int, n_iter: int = 20, seed: int = 1234) -> np.ndarray:
+def kmeans_ip(X: np.ndarray, n_lists: int, n_iter: int = 20, seed: int = 1234, init=None) -> np.ndarray:
     """Plain Lloyd k-means used by the build's own IVF trainer (centroids = mean of
-    members, assignment by max IP; empty lists re-seeded from the largest list).
+    members, assignment by max IP, lowest list id on ties; an empty list keeps its centroid).
+    `init` f32[n_lists,d] = starting centroids (default: seeded distinct rows).
     NOT faiss's trainer -- parity unpinned."""
     rng = np.random.RandomState(seed)
     n = X.shape[0]
-    C = X[rng.choice(n, n_lists, replace=False)].astype(np.float64).copy()
+    if init is not None:
+        C = np.asarray(init, dtype=np.float64).copy()
+    else:
+        C = X[rng.choice(n, n_lists, replace=False)].astype(np.float64).copy()
     for _ in range(n_iter):
         a = np.argmax(X.astype(np.float64) @ C.T, axis=1)
         for c in range(n_lists):

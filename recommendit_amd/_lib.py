@@ -71,6 +71,12 @@ SIGNATURES = {
     "rihip_ip_index_is_ivf": (C.c_int, [vp]),
     "rihip_ip_index_max_k": (C.c_int, []),
     "rihip_ip_index_train_ivf": (C.c_int, [vp, C.c_int, C.c_int, C.c_uint64, vp]),
+    "rihip_ip_index_nlist": (C.c_int, [vp]),
+    "rihip_ip_index_train_ivf_from": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
+    "rihip_ip_index_set_ivf": (C.c_int, [vp, C.c_int, vp, vp, vp]),
+    "rihip_ip_index_get_ivf": (C.c_int, [vp, vp, vp]),
+    "rihip_ip_index_reconstruct": (C.c_int, [vp, vp]),
+    "rihip_ip_index_assign": (C.c_int, [vp, vp, c_i64, vp, vp]),
     "rihip_ip_index_set_nprobe": (C.c_int, [vp, C.c_int]),
     "rihip_ip_index_set_two_precision": (C.c_int, [vp, C.c_int]),
     "rihip_ip_index_search": (C.c_int, [vp, vp, c_i64, C.c_int, vp, vp, vp]),

@@ -1,0 +1,72 @@
+// Handle of the inner-product index shared by topk.hip (search) and ivf.hip (k-means, list layout, state I/O).
+#pragma once
+#include "common.h"
+
+#include <vector>
+
+namespace rihip_index {
+
+constexpr int TR = 64;         // list granule: every IVF list is padded to a multiple of TR physical rows
+constexpr int TRS = 32;        // corpus rows per LDS tile of the exact-f32 scan kernel
+constexpr int K_MAX = 16384;   // largest k served by the device select/sort buffer (128 KiB of LDS)
+constexpr int NLIST_MAX = 2048;  // probe bitset: 64 words per query
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  int64_t n = 0;
+  int reserve(int64_t want) {
+    if (n >= want) return RIHIP_OK;
+    if (p) hipFree(p);
+    p = nullptr; n = 0;
+    if (hipMalloc((void**)&p, sizeof(T) * (size_t)want) != hipSuccess) {
+      rihip_set_error("ip_index: device allocation of %lld bytes failed", (long long)(sizeof(T) * (size_t)want));
+      return RIHIP_ERR_HIP;
+    }
+    n = want;
+    return RIHIP_OK;
+  }
+  void release() { if (p) hipFree(p); p = nullptr; n = 0; }
+};
+
+struct IpIndex {
+  int d = 0;
+  int64_t N = 0;         // real vectors
+  float* X = nullptr;    // brute force: [N,d]; IVF: [Np,d] list-ordered, zero-padded to 64-row granules
+  __bf16* Xb = nullptr;  // bf16 copy of X for the filter pass (flat index, N > 4*SAMPLE)
+  float max_norm = 0.f;  // max row 2-norm (error bound of the bf16 filter)
+  int two_precision = 1; // 1: bf16 filter + exact f32 re-score; 0: all-f32 search
+  DevBuf<float> qnorm;
+  // IVF
+  int nlist = 0, nprobe = 1;
+  bool ivf = false;
+  int64_t Np = 0;              // padded physical rows
+  float* C = nullptr;          // [nlist,d]
+  int* tile_list = nullptr;    // [Np/64] list of each granule
+  int* tile_nvalid = nullptr;  // [Np/32] real (non-padding) rows of each 32-row scan tile
+  int64_t* row_ids = nullptr;  // [Np] original row per physical row, -1 for padding
+  std::vector<int64_t> list_len;  // host copy
+  // scratch (grown on demand, owned by the handle)
+  DevBuf<uint64_t> cand, scand, fcand;
+  DevBuf<int> count, fail_flags, fail_list, n_fail, fcount;
+  DevBuf<float> thr, thr2, fQ;
+  DevBuf<uint32_t> probe_bits;
+  DevBuf<int> blk_tiles, blk_ntiles;
+  int* h_nfail = nullptr;  // pinned
+};
+
+inline void free_index_arrays(IpIndex* h) {
+  hipFree(h->X); hipFree(h->C); hipFree(h->tile_list); hipFree(h->tile_nvalid); hipFree(h->row_ids); hipFree(h->Xb);
+  h->X = nullptr; h->C = nullptr; h->tile_list = nullptr; h->tile_nvalid = nullptr; h->row_ids = nullptr; h->Xb = nullptr;
+  h->N = 0; h->Np = 0; h->ivf = false; h->nlist = 0; h->list_len.clear();
+}
+
+// flat index: (re)build the bf16 filter copy and the row-norm bound (topk.hip)
+int prepare_flat(IpIndex* h, hipStream_t st);
+// (re)derive tile_nvalid from row_ids after the lists were laid out or loaded (ivf.hip)
+int derive_tile_nvalid(IpIndex* h, hipStream_t st);
+
+}  // namespace rihip_index
+
+#define HIPCHK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { rihip_set_error("%s:%d %s", __FILE__, __LINE__, hipGetErrorString(_e)); return RIHIP_ERR_HIP; } } while (0)
+#define RCCHK(e) do { int _rc = (e); if (_rc) return _rc; } while (0)

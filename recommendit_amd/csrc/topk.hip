@@ -25,11 +25,13 @@
 #include <string>
 #include <vector>
 
+#include "ip_index.h"
+
+using namespace rihip_index;
+
 namespace {
 
-constexpr int TR = 64;          // corpus rows per LDS tile
 constexpr int QB = 128;         // queries per workgroup (32 per wave)
-constexpr int K_MAX = 2048;     // largest k served by the device sort buffer
 constexpr int SAMPLE = 16384;   // corpus rows scored for the threshold estimate
 
 __device__ __forceinline__ uint32_t f2ord(float f) {
@@ -62,6 +64,7 @@ struct ScanArgs {
   const uint32_t* probe_bits; // [nq, pb_words] bitset of probed lists
   int pb_words;
   const int64_t* row_ids;     // [N] original row id per physical row (IVF), or null
+  const int* tile_nvalid;     // [n_scan_tiles] real rows of each 32-row tile (list padding sits at the tile's end), or null
   const int* blk_tiles;       // [query blocks, n_scan_tiles] 32-row tiles some query of the block probes
   const int* blk_ntiles;      // [query blocks]
   int64_t n_scan_tiles;
@@ -69,7 +72,6 @@ struct ScanArgs {
   int qgrid;                  // bf16 filter: number of query blocks (1-D XCD-aware launch)
 };
 
-constexpr int TRS = 32;  // corpus rows per LDS tile of the scan kernel
 
 // 4 waves x 32 register-stationary queries share each 32-row corpus tile.  Same software pipeline as the
 // in-batch sweep: 3 LDS buffers, tile t+2 prefetched through registers, the S chain of tile t+1 interleaved with
@@ -139,7 +141,8 @@ __global__ __launch_bounds__(256, 2) void scan_kernel(ScanArgs a) {
       const int L = a.tile_list[tile >> 1];
       if (!((my_bits[L >> 5] >> (L & 31)) & 1u)) return;
     }
-    const int n_ok = (a.n_virtual - v_base) < TRS ? (int)(a.n_virtual - v_base) : TRS;
+    // list padding rows are never candidates (they would inflate count[q] and mask an under-filled list)
+    const int n_ok = a.tile_nvalid ? a.tile_nvalid[tile] : ((a.n_virtual - v_base) < TRS ? (int)(a.n_virtual - v_base) : TRS);
     unsigned hits = 0;  // per-lane aggregation: one atomic per (query, tile) that has survivors
 #pragma unroll
     for (int r = 0; r < 16; ++r)
@@ -514,7 +517,7 @@ struct FinArgs {
 
 __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
   __shared__ unsigned hist[256];
-  __shared__ uint64_t sbuf[K_MAX];
+  extern __shared__ __attribute__((aligned(16))) uint64_t sbuf[];  // [pow2 >= k] (mode 0 only)
   __shared__ unsigned s_bin, s_above, s_cnt;
   const int tid = threadIdx.x, lane = tid & 63;
   const int64_t qi = blockIdx.x;
@@ -594,7 +597,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
       const uint64_t key = keys[i];
       if (key > T) {
         const unsigned pos = atomicAdd(&s_cnt, 1u);
-        if (pos < (unsigned)K_MAX) sbuf[pos] = key;
+        if (pos < (unsigned)P) sbuf[pos] = key;
       }
     }
   }
@@ -649,116 +652,6 @@ __global__ void map_rows_kernel(int64_t* rows, int64_t n, const int64_t* __restr
   if (i < n) { const int64_t r = rows[i]; rows[i] = (r >= 0) ? ids[r] : -1; }
 }
 
-// ---------------------------------------- IVF build --------------------------------------------
-// assignment by max inner product with the centroid (IndexFlatIP quantizer); one wave per row
-__global__ __launch_bounds__(256) void ivf_assign_kernel(const float* __restrict__ X, int64_t N, int d,
-                                                         const float* __restrict__ C, int nlist, int* assign) {
-  extern __shared__ float Cs[];  // [nlist*d]
-  for (int i = threadIdx.x; i < nlist * d; i += 256) Cs[i] = C[i];
-  __syncthreads();
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < N; row += (int64_t)gridDim.x * 4) {
-    float best = -INFINITY;
-    int bi = 0;
-    for (int c = 0; c < nlist; ++c) {
-      float s = 0.f;
-      for (int k = lane; k < d; k += 64) s += X[row * d + k] * Cs[c * d + k];
-      s = wave_sum(s);
-      if (s > best) { best = s; bi = c; }
-    }
-    if (lane == 0) assign[row] = bi;
-  }
-}
-
-// MFMA form of the assignment (d in {32,64,128}): 4 waves x 32 register-stationary rows per workgroup, centroid tiles
-// of 32 through LDS, S[centroid][row] on exact-f32 MFMA, arg-max over the accumulator rows (lowest index wins ties).
-template <int D>
-__global__ __launch_bounds__(256, 2) void ivf_assign_mfma_kernel(const float* __restrict__ X, int64_t N,
-                                                                 const float* __restrict__ C, int nlist, int* assign) {
-  constexpr int LDC = D + 4, KB = D / 8;
-  constexpr int NV = (32 * (D / 4) + 255) / 256;
-  __shared__ __attribute__((aligned(16))) float Cs[32 * LDC];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int r31 = lane & 31, hh = lane >> 5;
-  const int ntile = (nlist + 31) / 32;
-  for (int64_t blk = blockIdx.x; blk * 128 < N; blk += gridDim.x) {
-    const int64_t row = blk * 128 + w * 32 + r31;
-    const int64_t rowc = row < N ? row : N - 1;
-    f32x4 xr[KB];
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) xr[kb] = *reinterpret_cast<const f32x4*>(&X[rowc * D + kb * 8 + 4 * hh]);
-    float best = -INFINITY;
-    int bi = 0;
-    for (int t = 0; t < ntile; ++t) {
-      __syncthreads();  // previous tile fully consumed
-#pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        const int idx = tid + i * 256;
-        const int r = idx / (D / 4), c4 = idx % (D / 4);
-        if (idx < 32 * (D / 4)) {
-          const int c = t * 32 + r;
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
-          if (c < nlist) v = reinterpret_cast<const f32x4*>(C + (size_t)c * D)[c4];
-          *reinterpret_cast<f32x4*>(&Cs[r * LDC + c4 * 4]) = v;
-        }
-      }
-      __syncthreads();
-      f32x16 acc = zero16();
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(&Cs[r31 * LDC + kb * 8 + 4 * hh]);
-        acc = mfma32(av.x, xr[kb].x, acc);
-        acc = mfma32(av.y, xr[kb].y, acc);
-        acc = mfma32(av.z, xr[kb].z, acc);
-        acc = mfma32(av.w, xr[kb].w, acc);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {  // acc_row(r, lane) grows with r: '>' keeps the lowest centroid on ties
-        const int c = t * 32 + acc_row(r, lane);
-        if (c < nlist && acc[r] > best) { best = acc[r]; bi = c; }
-      }
-    }
-    const float ob = __shfl_xor(best, 32, 64);
-    const int oi = __shfl_xor(bi, 32, 64);
-    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-    if (hh == 0 && row < N) assign[row] = bi;
-  }
-}
-
-// per-workgroup LDS accumulation of centroid sums, then one slab per workgroup (deterministic reduce)
-__global__ __launch_bounds__(256) void ivf_accum_kernel(const float* __restrict__ X, int64_t N, int d,
-                                                        const int* __restrict__ assign, int nlist, float* slab,
-                                                        int* cnt_slab) {
-  extern __shared__ float Ss[];  // [nlist*d] sums | [nlist] counts (as float bits of int)
-  int* Cn = reinterpret_cast<int*>(Ss + (size_t)nlist * d);
-  for (int i = threadIdx.x; i < nlist * d; i += 256) Ss[i] = 0.f;
-  for (int i = threadIdx.x; i < nlist; i += 256) Cn[i] = 0;
-  __syncthreads();
-  const int64_t per = (N + gridDim.x - 1) / gridDim.x;
-  const int64_t r0 = (int64_t)blockIdx.x * per, r1 = (r0 + per < N) ? r0 + per : N;
-  // rows processed in order by the whole block: thread t adds column t (and t+256...) => deterministic
-  for (int64_t row = r0; row < r1; ++row) {
-    const int c = assign[row];
-    for (int k = threadIdx.x; k < d; k += 256) Ss[c * d + k] += X[row * d + k];
-    if (threadIdx.x == 0) Cn[c] += 1;
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < nlist * d; i += 256) slab[(size_t)blockIdx.x * nlist * d + i] = Ss[i];
-  for (int i = threadIdx.x; i < nlist; i += 256) cnt_slab[(size_t)blockIdx.x * nlist + i] = Cn[i];
-}
-
-__global__ void ivf_update_kernel(const float* __restrict__ slab, const int* __restrict__ cnt_slab, int nslab, int nlist,
-                                  int d, float* C, int* counts, int update_c) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nlist * d) return;
-  const int c = i / d;
-  float s = 0.f;
-  int n = 0;
-  for (int k = 0; k < nslab; ++k) { s += slab[(size_t)k * nlist * d + i]; n += cnt_slab[(size_t)k * nlist + c]; }
-  if (update_c && n > 0) C[i] = s / (float)n;  // empty list keeps its previous centroid
-  if ((i % d) == 0) counts[c] = n;
-}
-
 // coarse quantizer: top-nprobe lists per query by IP -> probe bitset (one wave per query)
 __global__ __launch_bounds__(256) void ivf_probe_kernel(const float* __restrict__ Q, int64_t nq, int d,
                                                         const float* __restrict__ C, int nlist, int nprobe,
@@ -805,57 +698,6 @@ __global__ void fill_int_kernel(int* p, int64_t n, int v) {
   if (i < n) p[i] = v;
 }
 
-template <typename T>
-struct DevBuf {
-  T* p = nullptr;
-  int64_t n = 0;
-  int reserve(int64_t want) {
-    if (n >= want) return RIHIP_OK;
-    if (p) hipFree(p);
-    p = nullptr; n = 0;
-    if (hipMalloc((void**)&p, sizeof(T) * (size_t)want) != hipSuccess) {
-      rihip_set_error("ip_index: device allocation of %lld bytes failed", (long long)(sizeof(T) * (size_t)want));
-      return RIHIP_ERR_HIP;
-    }
-    n = want;
-    return RIHIP_OK;
-  }
-  void release() { if (p) hipFree(p); p = nullptr; n = 0; }
-};
-
-struct IpIndex {
-  int d = 0;
-  int64_t N = 0;         // real vectors
-  float* X = nullptr;    // brute force: [N,d]; IVF: [Np,d] list-ordered, zero-padded to 64-row tiles
-  __bf16* Xb = nullptr;  // bf16 copy of X for the filter pass (flat index, N > 4*SAMPLE)
-  float max_norm = 0.f;  // max row 2-norm (error bound of the bf16 filter)
-  int two_precision = 1; // 1: bf16 filter + exact f32 re-score; 0: all-f32 search
-  DevBuf<float> qnorm;
-  // IVF
-  int nlist = 0, nprobe = 1;
-  bool ivf = false;
-  int64_t Np = 0;              // padded physical rows
-  float* C = nullptr;          // [nlist,d]
-  int* tile_list = nullptr;    // [Np/64]
-  int64_t* row_ids = nullptr;  // [Np] original row per physical row, -1 for padding
-  std::vector<int64_t> list_len;  // host copy
-  // scratch (grown on demand, owned by the handle)
-  DevBuf<uint64_t> cand, scand, fcand;
-  DevBuf<int> count, fail_flags, fail_list, n_fail, fcount;
-  DevBuf<float> thr, thr2, fQ;
-  DevBuf<uint32_t> probe_bits;
-  DevBuf<int> blk_tiles, blk_ntiles;
-  int* h_nfail = nullptr;  // pinned
-};
-
-#define HIPCHK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { rihip_set_error("%s:%d %s", __FILE__, __LINE__, hipGetErrorString(_e)); return RIHIP_ERR_HIP; } } while (0)
-#define RCCHK(e) do { int _rc = (e); if (_rc) return _rc; } while (0)
-
-void free_index_arrays(IpIndex* h) {
-  hipFree(h->X); hipFree(h->C); hipFree(h->tile_list); hipFree(h->row_ids); hipFree(h->Xb);
-  h->X = nullptr; h->C = nullptr; h->tile_list = nullptr; h->row_ids = nullptr; h->Xb = nullptr;
-  h->N = 0; h->Np = 0; h->ivf = false; h->list_len.clear();
-}
 
 template <int D>
 void launch_scan(const ScanArgs& a, dim3 grid, hipStream_t st) {
@@ -874,6 +716,24 @@ int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { rihip_set_error("%s launch: %s", what, hipGetErrorString(e)); return RIHIP_ERR_HIP; }
   return RIHIP_OK;
+}
+
+// finalize launch: the sort buffer is dynamic LDS sized to the power of two >= k (mode 0); mode 1 needs none
+int launch_finalize(const FinArgs& f, unsigned n, hipStream_t st) {
+  size_t lds = 0;
+  if (f.mode == 0) {
+    int P = 64;
+    while (P < f.k) P <<= 1;
+    lds = sizeof(uint64_t) * (size_t)P;
+    static bool granted = false;
+    if (!granted) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(sizeof(uint64_t) * K_MAX));
+      granted = true;
+    }
+  }
+  hipLaunchKernelGGL(finalize_kernel, dim3(n), dim3(256), lds, st, f);
+  return check_launch("finalize");
 }
 
 int pick_nsplit(int64_t nq, int64_t n_tiles) {
@@ -922,7 +782,7 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
       memset(&x, 0, sizeof(x));
       x.X = h->X; x.Q = Qp; x.nq = n; x.count = h->count.p; x.n_virtual = Nphys; x.row_stride = 1; x.thr = thr;
       x.cand = cand; x.cap = cap; x.dense = 0; x.tile_list = h->tile_list; x.probe_bits = h->probe_bits.p;
-      x.pb_words = pbw; x.row_ids = h->row_ids; x.blk_tiles = h->blk_tiles.p; x.blk_ntiles = h->blk_ntiles.p;
+      x.pb_words = pbw; x.row_ids = h->row_ids; x.tile_nvalid = h->tile_nvalid; x.blk_tiles = h->blk_tiles.p; x.blk_ntiles = h->blk_ntiles.p;
       x.n_scan_tiles = n_scan_tiles; x.tile_step = tile_step;
       const int64_t est = (n_scan_tiles * h->nprobe) / (h->nlist > 0 ? h->nlist : 1) / (tile_step > 1 ? tile_step : 1) + 1;
       x.nsplit = pick_nsplit(n, est);
@@ -949,7 +809,7 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
       memset(&f2, 0, sizeof(f2));
       f2.nq = n; f2.k = k; f2.count = h->count.p; f2.out_scores = out_s; f2.out_rows = out_r; f2.cand = h->fcand.p;
       f2.cap = cap_full; f2.mode = 0; f2.out_slot = out_slot;
-      hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)n), dim3(256), 0, st, f2);
+      RCCHK(launch_finalize(f2, (unsigned)n, st));
       return check_launch("finalize");
     };
     const int SS = 16;  // threshold sample: every 16th probed tile
@@ -966,11 +826,11 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
     RCCHK(ivf_prepare(Q, nq));
     RCCHK(ivf_scan(Q, nq, nullptr, h->scand.p, cap_s, SS));                      // pass A: sampled tiles, no filter
     fa.cand = h->scand.p; fa.cap = cap_s; fa.mode = 1; fa.rank = rank; fa.thr_out = h->thr.p;
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3(256), 0, st, fa);
+    RCCHK(launch_finalize(fa, (unsigned)nq, st));
     RCCHK(ivf_scan(Q, nq, h->thr.p, h->cand.p, cap, 1));                         // pass B: all probed tiles, filtered
     fa.cand = h->cand.p; fa.cap = cap; fa.mode = 0; fa.thr_out = nullptr; fa.fail_flags = h->fail_flags.p;
     fa.ivf_thr = h->thr.p;
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3(256), 0, st, fa);
+    RCCHK(launch_finalize(fa, (unsigned)nq, st));
     hipLaunchKernelGGL(fill_int_kernel, dim3(1), dim3(64), 0, st, h->n_fail.p, 1, 0);
     hipLaunchKernelGGL(collect_fail_kernel, dim3(nqb), dim3(256), 0, st, h->fail_flags.p, nq, h->fail_list.p, h->n_fail.p);
     RCCHK(check_launch("finalize"));
@@ -998,7 +858,7 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
     sa.nsplit = pick_nsplit(nq, n_tiles);
     RCCHK(dispatch_scan(d, sa, dim3(qgrid, sa.nsplit), st));
     fa.cand = h->cand.p; fa.cap = h->N; fa.mode = 0;
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3(256), 0, st, fa);
+    RCCHK(launch_finalize(fa, (unsigned)nq, st));
     return check_launch("finalize");
   }
 
@@ -1047,7 +907,7 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
   sa.n_virtual = S; sa.row_stride = stride; sa.thr = nullptr; sa.cand = h->scand.p; sa.cap = S; sa.dense = 1;
   RCCHK(run_scan(sa, (S + (two_prec ? TRB : TRS) - 1) / (two_prec ? TRB : TRS)));
   fa.cand = h->scand.p; fa.cap = S; fa.mode = 1; fa.rank = rank; fa.thr_out = h->thr.p;
-  hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3(256), 0, st, fa);
+  RCCHK(launch_finalize(fa, (unsigned)nq, st));
   // ---- pass 1: thresholded scan (atomic append of the rare survivors)
   hipLaunchKernelGGL(fill_int_kernel, dim3(nqb), dim3(256), 0, st, h->count.p, nq, 0);
   sa.n_virtual = h->N; sa.row_stride = 1; sa.thr = h->thr.p; sa.cand = h->cand.p; sa.cap = cap; sa.dense = 0;
@@ -1060,7 +920,7 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
       FinArgs f2 = fa;
       f2.cand = h->cand.p; f2.cap = cap; f2.mode = 1; f2.rank = k; f2.thr_out = h->thr2.p; f2.fail_flags = nullptr;
       f2.thr_chk = nullptr; f2.qnorm = nullptr; f2.ivf_thr = nullptr; f2.need_min = 0;
-      hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3(256), 0, st, f2);
+      RCCHK(launch_finalize(f2, (unsigned)nq, st));
     }
     const float eps_sc = (float)((1.0 / 256.0 + 1.0 / 262144.0) * (double)h->max_norm * 1.001);
     if (d == 32) hipLaunchKernelGGL((rerank_kernel<32>), dim3((unsigned)nq), dim3(256), 0, st, h->X, Q, h->cand.p, cap, h->count.p, h->qnorm.p, h->N, h->thr2.p, eps_sc);
@@ -1072,7 +932,7 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
   // ---- pass 2: finalize + exactness flags
   fa.cand = h->cand.p; fa.cap = cap; fa.mode = 0; fa.fail_flags = h->fail_flags.p;
   fa.need_min = k < h->N ? k : h->N; fa.thr_out = nullptr;
-  hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nq), dim3(256), 0, st, fa);
+  RCCHK(launch_finalize(fa, (unsigned)nq, st));
   hipLaunchKernelGGL(fill_int_kernel, dim3(1), dim3(64), 0, st, h->n_fail.p, 1, 0);
   hipLaunchKernelGGL(collect_fail_kernel, dim3(nqb), dim3(256), 0, st, h->fail_flags.p, nq, h->fail_list.p, h->n_fail.p);
   RCCHK(check_launch("finalize"));
@@ -1098,7 +958,7 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
       memset(&ff, 0, sizeof(ff));
       ff.cand = h->fcand.p; ff.cap = h->N; ff.count = h->fcount.p; ff.nq = nfc; ff.k = k; ff.mode = 0;
       ff.out_scores = out_s; ff.out_rows = out_r; ff.out_slot = h->fail_list.p + f0;
-      hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)nfc), dim3(256), 0, st, ff);
+      RCCHK(launch_finalize(ff, (unsigned)nfc, st));
     }
     RCCHK(check_launch("fallback"));
   }
@@ -1106,6 +966,30 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
 }
 
 }  // namespace
+
+namespace rihip_index {
+// flat index with N > 4*SAMPLE: the bf16 filter copy of the two-precision search + the row-norm bound it needs
+int prepare_flat(IpIndex* h, hipStream_t st) {
+  if (h->ivf || h->N <= 4 * (int64_t)SAMPLE) return RIHIP_OK;
+  const int64_t n = h->N * h->d;
+  hipFree(h->Xb);
+  h->Xb = nullptr;
+  HIPCHK(hipMalloc((void**)&h->Xb, sizeof(__bf16) * (size_t)n));
+  hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, st, h->X, n, h->Xb);
+  int* bits = nullptr;
+  HIPCHK(hipMalloc((void**)&bits, sizeof(int)));
+  HIPCHK(hipMemsetAsync(bits, 0, sizeof(int), st));
+  hipLaunchKernelGGL(rownorm_max_kernel, dim3(1024), dim3(256), 0, st, h->X, h->N, h->d, bits);
+  int hb = 0;
+  HIPCHK(hipMemcpyAsync(&hb, bits, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  hipFree(bits);
+  float sq;
+  memcpy(&sq, &hb, sizeof(float));
+  h->max_norm = sqrtf(sq);
+  return RIHIP_OK;
+}
+}  // namespace rihip_index
 
 extern "C" int rihip_ip_index_create(int d, void** handle) {
   RIHIP_REQUIRE(handle, RIHIP_ERR_ARG, "ip_index_create: null handle");
@@ -1138,23 +1022,7 @@ extern "C" int rihip_ip_index_set_vectors(void* handle, const float* X, int64_t 
                         (hipStream_t)stream));
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   h->N = N;
-  if (N > 4 * (int64_t)SAMPLE) {  // two-precision search: bf16 filter copy + the row-norm bound it needs
-    hipStream_t st = (hipStream_t)stream;
-    const int64_t n = N * h->d;
-    HIPCHK(hipMalloc((void**)&h->Xb, sizeof(__bf16) * (size_t)n));
-    hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, st, h->X, n, h->Xb);
-    int* bits = nullptr;
-    HIPCHK(hipMalloc((void**)&bits, sizeof(int)));
-    HIPCHK(hipMemsetAsync(bits, 0, sizeof(int), st));
-    hipLaunchKernelGGL(rownorm_max_kernel, dim3(1024), dim3(256), 0, st, h->X, N, h->d, bits);
-    int hb = 0;
-    HIPCHK(hipMemcpyAsync(&hb, bits, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    hipFree(bits);
-    float sq;
-    memcpy(&sq, &hb, sizeof(float));
-    h->max_norm = sqrtf(sq);
-  }
+  RCCHK(prepare_flat(h, (hipStream_t)stream));
   return RIHIP_OK;
 }
 
@@ -1198,163 +1066,5 @@ extern "C" int rihip_map_rows_to_ids(int64_t* rows, int64_t n, const int64_t* it
   if (n == 0) return RIHIP_OK;
   hipLaunchKernelGGL(map_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows, n, item_ids);
   RIHIP_CHECK_LAUNCH();
-  return RIHIP_OK;
-}
-
-// k-means (IP assignment, mean update) + list-contiguous re-ordering.  Deterministic given seed.
-extern "C" int rihip_ip_index_train_ivf(void* handle, int nlist, int n_iter, uint64_t seed, void* stream) {
-  IpIndex* h = (IpIndex*)handle;
-  RIHIP_REQUIRE(h && h->X && !h->ivf, RIHIP_ERR_STATE, "ip_index_train_ivf: needs a flat, non-empty index");
-  RIHIP_REQUIRE(nlist >= 1 && nlist <= h->N, RIHIP_ERR_ARG, "ip_index_train_ivf: nlist=%d for N=%lld", nlist, (long long)h->N);
-  const int d = h->d;
-  RIHIP_REQUIRE((size_t)nlist * d * 4 + nlist * 4 <= 64 * 1024, RIHIP_ERR_SHAPE,
-                "ip_index_train_ivf: nlist*d*4 must fit 64 KiB of LDS (nlist=%d, d=%d)", nlist, d);
-  hipStream_t st = (hipStream_t)stream;
-  const int64_t N = h->N;
-  // initial centroids: nlist distinct rows picked by a seeded LCG over a strided lattice
-  std::vector<int64_t> pick(nlist);
-  {
-    uint64_t s = rihip_splitmix64(seed);
-    const int64_t step = N / nlist;
-    for (int c = 0; c < nlist; ++c) { s = rihip_splitmix64(s); pick[c] = (int64_t)c * step + (int64_t)(s % (uint64_t)step); }
-  }
-  HIPCHK(hipMalloc((void**)&h->C, sizeof(float) * nlist * d));
-  for (int c = 0; c < nlist; ++c)
-    HIPCHK(hipMemcpyAsync(h->C + (size_t)c * d, h->X + (size_t)pick[c] * d, sizeof(float) * d, hipMemcpyDeviceToDevice, st));
-  int* assign = nullptr; float* slab = nullptr; int* cnt_slab = nullptr; int* counts = nullptr;
-  const int NSL = 768;  // 3 workgroups per CU (LDS-bound), one deterministic slab each
-  HIPCHK(hipMalloc((void**)&assign, sizeof(int) * N));
-  HIPCHK(hipMalloc((void**)&slab, sizeof(float) * (size_t)NSL * nlist * d));
-  HIPCHK(hipMalloc((void**)&cnt_slab, sizeof(int) * (size_t)NSL * nlist));
-  HIPCHK(hipMalloc((void**)&counts, sizeof(int) * nlist));
-  const size_t lds_c = sizeof(float) * nlist * d;
-  const int agrid = (int)((N + 3) / 4 < 2048 ? (N + 3) / 4 : 2048);
-  for (int it = 0; it <= n_iter; ++it) {
-    {
-      const int64_t nblk = (N + 127) / 128;
-      const dim3 mg((unsigned)(nblk < 2048 ? nblk : 2048));
-      if (d == 128) hipLaunchKernelGGL((ivf_assign_mfma_kernel<128>), mg, dim3(256), 0, st, h->X, N, h->C, nlist, assign);
-      else if (d == 64) hipLaunchKernelGGL((ivf_assign_mfma_kernel<64>), mg, dim3(256), 0, st, h->X, N, h->C, nlist, assign);
-      else if (d == 32) hipLaunchKernelGGL((ivf_assign_mfma_kernel<32>), mg, dim3(256), 0, st, h->X, N, h->C, nlist, assign);
-      else hipLaunchKernelGGL(ivf_assign_kernel, dim3(agrid), dim3(256), lds_c, st, h->X, N, d, h->C, nlist, assign);
-    }
-    hipLaunchKernelGGL(ivf_accum_kernel, dim3(NSL), dim3(256), lds_c + sizeof(int) * nlist, st, h->X, N, d, assign, nlist, slab, cnt_slab);
-    if (it == n_iter) {  // final assignment: only the counts are needed
-      hipLaunchKernelGGL(ivf_update_kernel, dim3((nlist * d + 255) / 256), dim3(256), 0, st, slab, cnt_slab, NSL, nlist, d, h->C, counts, 0);
-      break;
-    }
-    hipLaunchKernelGGL(ivf_update_kernel, dim3((nlist * d + 255) / 256), dim3(256), 0, st, slab, cnt_slab, NSL, nlist, d, h->C, counts, 1);
-  }
-  {
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { rihip_set_error("ivf train launch: %s", hipGetErrorString(e)); return RIHIP_ERR_HIP; }
-  }
-  // host-side list layout (N ints; build-time only)
-  std::vector<int> h_assign(N), h_counts(nlist);
-  HIPCHK(hipMemcpyAsync(h_assign.data(), assign, sizeof(int) * N, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(h_counts.data(), counts, sizeof(int) * nlist, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  std::vector<int64_t> off(nlist + 1, 0);
-  h->list_len.assign(nlist, 0);
-  for (int c = 0; c < nlist; ++c) {
-    h->list_len[c] = h_counts[c];
-    off[c + 1] = off[c] + ((int64_t)h_counts[c] + TR - 1) / TR * TR;
-  }
-  const int64_t Np = off[nlist] > 0 ? off[nlist] : TR;
-  std::vector<int64_t> rid(Np, -1);
-  std::vector<int> tl(Np / TR, 0);
-  {
-    std::vector<int64_t> cur(off.begin(), off.end() - 1);
-    for (int64_t r = 0; r < N; ++r) rid[cur[h_assign[r]]++] = r;  // ascending original row inside a list
-    for (int c = 0; c < nlist; ++c)
-      for (int64_t t = off[c] / TR; t < off[c + 1] / TR; ++t) tl[t] = c;
-  }
-  float* Xn = nullptr;
-  HIPCHK(hipMalloc((void**)&Xn, sizeof(float) * (size_t)Np * d));
-  HIPCHK(hipMemsetAsync(Xn, 0, sizeof(float) * (size_t)Np * d, st));
-  HIPCHK(hipMalloc((void**)&h->row_ids, sizeof(int64_t) * Np));
-  HIPCHK(hipMalloc((void**)&h->tile_list, sizeof(int) * (Np / TR)));
-  HIPCHK(hipMemcpyAsync(h->row_ids, rid.data(), sizeof(int64_t) * Np, hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(h->tile_list, tl.data(), sizeof(int) * (Np / TR), hipMemcpyHostToDevice, st));
-  // permute rows on device: contiguous runs per list are copied row by row via a gather kernel
-  {
-    std::vector<int> src(Np);
-    for (int64_t i = 0; i < Np; ++i) src[i] = rid[i] >= 0 ? (int)rid[i] : -1;
-    int* d_src = nullptr;
-    HIPCHK(hipMalloc((void**)&d_src, sizeof(int) * Np));
-    HIPCHK(hipMemcpyAsync(d_src, src.data(), sizeof(int) * Np, hipMemcpyHostToDevice, st));
-    // reuse gather_rows_kernel for valid rows: padding rows (src=-1) are remapped to row 0 then zeroed by row_ids=-1 filter
-    for (int64_t i = 0; i < Np; ++i) if (src[i] < 0) src[i] = 0;
-    HIPCHK(hipMemcpyAsync(d_src, src.data(), sizeof(int) * Np, hipMemcpyHostToDevice, st));
-    const int64_t tot = Np * d;
-    for (int64_t o = 0; o < Np; o += (1 << 20)) {
-      const int64_t n = (Np - o < (1 << 20)) ? Np - o : (1 << 20);
-      hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n * d + 255) / 256)), dim3(256), 0, st, h->X, d_src + o, (int)n, d, Xn + o * d);
-    }
-    (void)tot;
-    HIPCHK(hipStreamSynchronize(st));
-    hipFree(d_src);
-  }
-  hipFree(assign); hipFree(slab); hipFree(cnt_slab); hipFree(counts);
-  hipFree(h->X);
-  h->X = Xn; h->Np = Np; h->nlist = nlist; h->ivf = true;
-  return RIHIP_OK;
-}
-
-// ---- persistence: own binary format ("RIHIPIDX" v1); the .meta.pkl sidecar stays with the Python wrapper
-extern "C" int rihip_ip_index_save(void* handle, const char* path) {
-  IpIndex* h = (IpIndex*)handle;
-  RIHIP_REQUIRE(h && h->X && path, RIHIP_ERR_STATE, "ip_index_save: empty index");
-  FILE* f = fopen(path, "wb");
-  RIHIP_REQUIRE(f, RIHIP_ERR_IO, "ip_index_save: cannot open %s", path);
-  const int64_t rows = h->ivf ? h->Np : h->N;
-  std::vector<float> X((size_t)rows * h->d);
-  hipMemcpy(X.data(), h->X, sizeof(float) * X.size(), hipMemcpyDeviceToHost);
-  const char magic[8] = {'R', 'I', 'H', 'I', 'P', 'I', 'D', 'X'};
-  int64_t hdr[8] = {1, h->d, h->N, h->ivf ? 1 : 0, h->nlist, h->nprobe, h->Np, 0};
-  fwrite(magic, 1, 8, f); fwrite(hdr, sizeof(int64_t), 8, f); fwrite(X.data(), sizeof(float), X.size(), f);
-  if (h->ivf) {
-    std::vector<float> C((size_t)h->nlist * h->d); std::vector<int> tl(h->Np / TR); std::vector<int64_t> rid(h->Np);
-    hipMemcpy(C.data(), h->C, sizeof(float) * C.size(), hipMemcpyDeviceToHost);
-    hipMemcpy(tl.data(), h->tile_list, sizeof(int) * tl.size(), hipMemcpyDeviceToHost);
-    hipMemcpy(rid.data(), h->row_ids, sizeof(int64_t) * rid.size(), hipMemcpyDeviceToHost);
-    fwrite(C.data(), sizeof(float), C.size(), f); fwrite(tl.data(), sizeof(int), tl.size(), f);
-    fwrite(rid.data(), sizeof(int64_t), rid.size(), f); fwrite(h->list_len.data(), sizeof(int64_t), h->nlist, f);
-  }
-  const bool ok = !ferror(f);
-  fclose(f);
-  RIHIP_REQUIRE(ok, RIHIP_ERR_IO, "ip_index_save: write error on %s", path);
-  return RIHIP_OK;
-}
-
-extern "C" int rihip_ip_index_load(const char* path, void** handle) {
-  RIHIP_REQUIRE(path && handle, RIHIP_ERR_ARG, "ip_index_load: bad arguments");
-  FILE* f = fopen(path, "rb");
-  RIHIP_REQUIRE(f, RIHIP_ERR_IO, "ip_index_load: cannot open %s", path);
-  char magic[8]; int64_t hdr[8];
-  if (fread(magic, 1, 8, f) != 8 || memcmp(magic, "RIHIPIDX", 8) != 0 || fread(hdr, sizeof(int64_t), 8, f) != 8 || hdr[0] != 1) {
-    fclose(f); rihip_set_error("ip_index_load: %s is not a RIHIPIDX v1 file", path); return RIHIP_ERR_IO;
-  }
-  IpIndex* h = new IpIndex();
-  h->d = (int)hdr[1]; h->N = hdr[2]; h->ivf = hdr[3] != 0; h->nlist = (int)hdr[4]; h->nprobe = (int)hdr[5]; h->Np = hdr[6];
-  const int64_t rows = h->ivf ? h->Np : h->N;
-  std::vector<float> X((size_t)rows * h->d);
-  bool ok = fread(X.data(), sizeof(float), X.size(), f) == X.size();
-  if (ok) { ok = hipMalloc((void**)&h->X, sizeof(float) * X.size()) == hipSuccess && hipMemcpy(h->X, X.data(), sizeof(float) * X.size(), hipMemcpyHostToDevice) == hipSuccess; }
-  if (ok && h->ivf) {
-    std::vector<float> C((size_t)h->nlist * h->d); std::vector<int> tl(h->Np / TR); std::vector<int64_t> rid(h->Np);
-    h->list_len.assign(h->nlist, 0);
-    ok = fread(C.data(), sizeof(float), C.size(), f) == C.size() && fread(tl.data(), sizeof(int), tl.size(), f) == tl.size() &&
-         fread(rid.data(), sizeof(int64_t), rid.size(), f) == rid.size() &&
-         fread(h->list_len.data(), sizeof(int64_t), h->nlist, f) == (size_t)h->nlist;
-    if (ok) ok = hipMalloc((void**)&h->C, sizeof(float) * C.size()) == hipSuccess && hipMalloc((void**)&h->tile_list, sizeof(int) * tl.size()) == hipSuccess &&
-                 hipMalloc((void**)&h->row_ids, sizeof(int64_t) * rid.size()) == hipSuccess &&
-                 hipMemcpy(h->C, C.data(), sizeof(float) * C.size(), hipMemcpyHostToDevice) == hipSuccess &&
-                 hipMemcpy(h->tile_list, tl.data(), sizeof(int) * tl.size(), hipMemcpyHostToDevice) == hipSuccess &&
-                 hipMemcpy(h->row_ids, rid.data(), sizeof(int64_t) * rid.size(), hipMemcpyHostToDevice) == hipSuccess;
-  }
-  fclose(f);
-  if (!ok) { rihip_ip_index_destroy(h); rihip_set_error("ip_index_load: truncated file or allocation failure: %s", path); return RIHIP_ERR_IO; }
-  *handle = h;
   return RIHIP_OK;
 }

@@ -86,8 +86,12 @@ class FAISSIndex:
         self._item_id_to_faiss_idx = {int(iid): idx for idx, iid in enumerate(item_ids)}
 
     def build_from_device(self, x_dev: torch.Tensor, item_ids: np.ndarray, kmeans_iters: int = 20,
-                          seed: int = 1234) -> None:
-        """Build from already-normalised f32 [N,d] rows on the device (no host round trip)."""
+                          seed: int = 1234, init_centroids: Optional[np.ndarray] = None,
+                          centroids: Optional[np.ndarray] = None, assign: Optional[np.ndarray] = None) -> None:
+        """Build from already-normalised f32 [N,d] rows on the device (no host round trip).
+
+        init_centroids f32[n_lists,d]: k-means starts from these instead of seeded rows (kmeans_iters=0 partitions
+        by them as they are).  centroids + assign int32[N]: inject a trained partition (a FAISS IndexIVFFlat file)."""
         lib = L.lib()
         n = x_dev.shape[0]
         assert x_dev.dtype == torch.float32 and x_dev.shape[1] == self.embed_dim and x_dev.is_contiguous()
@@ -99,18 +103,61 @@ class FAISSIndex:
         if not self.exact:
             nlist = max(1, min(self.n_lists, n))
             logger.info("Training IVF index on %d vectors (n_lists=%d)...", n, nlist)
-            L.check(lib.rihip_ip_index_train_ivf(self.index._h, nlist, kmeans_iters, seed, L.stream_ptr()),
-                    "ip_index_train_ivf")
+            if centroids is not None:
+                c = np.ascontiguousarray(centroids, dtype=np.float32)
+                a = np.ascontiguousarray(assign, dtype=np.int32)
+                assert c.shape == (nlist, self.embed_dim) and a.shape == (n,)
+                L.check(lib.rihip_ip_index_set_ivf(self.index._h, nlist, c.ctypes.data, a.ctypes.data, L.stream_ptr()),
+                        "ip_index_set_ivf")
+            elif init_centroids is not None:
+                c = np.ascontiguousarray(init_centroids, dtype=np.float32)
+                assert c.shape == (nlist, self.embed_dim)
+                L.check(lib.rihip_ip_index_train_ivf_from(self.index._h, nlist, kmeans_iters, c.ctypes.data,
+                                                          L.stream_ptr()), "ip_index_train_ivf_from")
+            else:
+                L.check(lib.rihip_ip_index_train_ivf(self.index._h, nlist, kmeans_iters, seed, L.stream_ptr()),
+                        "ip_index_train_ivf")
         L.check(lib.rihip_ip_index_set_nprobe(self.index._h, int(self.n_probe)), "ip_index_set_nprobe")
         self.item_ids = np.asarray(item_ids, dtype=np.int64)
         self._item_ids_dev = torch.from_numpy(self.item_ids).to(x_dev.device)
         logger.info("Index built: %d vectors, %d lists, probe=%d", self.index.ntotal, self.n_lists, self.n_probe)
+
+    # -- trained state (what faiss exposes as index.quantizer / index.invlists) ------------------
+    def centroids(self) -> np.ndarray:
+        """f32 [nlist,d] coarse centroids of the IVF partition."""
+        nl = int(L.lib().rihip_ip_index_nlist(self.index._h))
+        c = np.empty((nl, self.embed_dim), dtype=np.float32)
+        L.check(L.lib().rihip_ip_index_get_ivf(self.index._h, c.ctypes.data, None), "ip_index_get_ivf")
+        return c
+
+    def list_assignment(self) -> np.ndarray:
+        """int32 [N]: the inverted list every stored row (insertion order) belongs to."""
+        a = np.empty(self.index.ntotal, dtype=np.int32)
+        L.check(L.lib().rihip_ip_index_get_ivf(self.index._h, None, a.ctypes.data), "ip_index_get_ivf")
+        return a
+
+    def reconstruct(self) -> np.ndarray:
+        """f32 [N,d]: the stored (normalised) vectors in insertion order (faiss reconstruct_n(0, ntotal))."""
+        x = np.empty((self.index.ntotal, self.embed_dim), dtype=np.float32)
+        L.check(L.lib().rihip_ip_index_reconstruct(self.index._h, x.ctypes.data), "ip_index_reconstruct")
+        return x
+
+    def assign_lists(self, x_dev: torch.Tensor) -> torch.Tensor:
+        """int32 [n] on device: arg-max-IP list of each f32 [n,d] device row (the IndexFlatIP quantizer)."""
+        x = x_dev.to(dtype=torch.float32).contiguous()
+        out = torch.empty(x.shape[0], dtype=torch.int32, device=x.device)
+        L.check(L.lib().rihip_ip_index_assign(self.index._h, x.data_ptr(), x.shape[0], out.data_ptr(), L.stream_ptr()),
+                "ip_index_assign")
+        return out
 
     # -- search (faiss_index.py:88-153) -------------------------------------------------------
     def _search_device(self, q_dev: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
         """q_dev: normalised f32 [nq,d] on device -> (scores [nq,k], rows [nq,k]) on device."""
         lib = L.lib()
         nq = q_dev.shape[0]
+        if k > int(lib.rihip_ip_index_max_k()):
+            raise ValueError(f"k={k} exceeds the device select buffer ({int(lib.rihip_ip_index_max_k())}); "
+                             "the reference (faiss) has no such limit -- see INTEGRATION.md")
         scores = torch.empty((nq, k), dtype=torch.float32, device=q_dev.device)
         rows = torch.empty((nq, k), dtype=torch.int64, device=q_dev.device)
         L.check(lib.rihip_ip_index_search(self.index._h, q_dev.data_ptr(), nq, k, scores.data_ptr(), rows.data_ptr(),
