@@ -56,9 +56,9 @@ def _compare_search(idx, Q, X, nprobe, k, min_checked=0.9):
             continue
         # order/membership may differ only among float near-ties
         diff = np.nonzero(rows[q, :n_ok] != o_r[q, :n_ok])[0]
-        for i in diff:
-            lo, hi = max(i - 1, 0), min(i + 1, n_ok - 1)
-            assert abs(o_s[q, lo] - o_s[q, hi]) < 8 * TOL or i == n_ok - 1, (q, i)
+        for i in diff:                                   # position i ties with a neighbour (f32 vs f64 rounding)
+            gaps = [abs(float(o_s[q, i]) - float(o_s[q, j])) for j in (i - 1, i + 1) if 0 <= j < n_ok]
+            assert min(gaps) < 4 * TOL or i == n_ok - 1, (q, i, gaps)
         extra = set(rows[q, :n_ok].tolist()) ^ set(o_r[q, :n_ok].tolist())
         if extra:                                       # a swap across the k-th boundary: scores equal within TOL
             true = X[sorted(extra)].astype(np.float64) @ Q[q].astype(np.float64)
@@ -197,7 +197,8 @@ def test_ivf_underfill_not_masked_by_list_padding():
     from recommendit_amd import FAISSIndex
     rng = np.random.RandomState(38)
     d, nlist, nprobe, k = 64, 20, 10, 500
-    C = fx.unit_rows(rng, nlist, d)
+    m = fx.unit_rows(rng, 1, d)
+    C = R.normalize_rows(m + fx.unit_rows(rng, nlist, d))     # every centroid inside a cone around m
     per = 64 * 60 + 1                                          # 3841 rows per list -> 63 padding rows each; large
     # enough (10 x 3904 probed rows) for the sampled-threshold scan, where a zero-score padding row passes thr <= 0
     X = np.concatenate([R.normalize_rows(C[c] + 0.3 * rng.randn(per, d).astype(np.float32) / np.sqrt(d))
@@ -206,6 +207,6 @@ def test_ivf_underfill_not_masked_by_list_padding():
     perm = rng.permutation(len(X)); X, a = X[perm], a[perm]
     idx = FAISSIndex(embed_dim=d, n_lists=nlist, n_probe=nprobe)
     idx.build_from_device(torch.from_numpy(X).cuda(), np.arange(len(X)), centroids=C, assign=a)
-    Q = R.normalize_rows(-(C[:8] + C[8:16]))                    # negative scores against every probed list
+    Q = R.normalize_rows(-m + 0.2 * fx.unit_rows(rng, 8, d))   # negative scores against every list
     sc, rows, o_s, o_r = _compare_search(idx, Q, X, nprobe, k, min_checked=0.5)
-    assert (rows >= 0).all() and (sc < 0).mean() > 0.5
+    assert (rows >= 0).all() and (sc < 0).all()
