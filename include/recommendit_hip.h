@@ -166,6 +166,19 @@ int rihip_adam_rows(float* table, float* m, float* v, const int64_t* uniq, const
                     void* workspace, float lr, float beta1, float beta2, float eps, float weight_decay,
                     int64_t step, const float* clip_coef, const float* hyper_dev, void* stream);
 
+/* ---- row-sharded tables (multi-GPU; BASELINE cfg4) ---------------------------------------------
+ * The reference keeps each embedding table on one device (src/models/two_tower.py:27,:54; device picked at
+ * src/training/train_embeddings.py:102-109).  Cut by rows over `world` ranks, global row g >= 1 lives on rank
+ * (g-1) % world at local row (g-1)/world + 1 (local row 0 = unused padding).  route_rows sorts a batch of global
+ * ids by owner (stable): sorted_local int64[B] = owner-local rows in send order, perm int64[B] = pair of each send
+ * slot, pos int64[B] = send slot of each pair (the ids the tower kernels use on the received-row staging table),
+ * counts int64[world] = requests per owner (the all-to-all split sizes).  gather_rows: out[i] = table[ids[i]]. */
+int64_t rihip_route_workspace_bytes(int64_t B);
+int rihip_route_rows(const int64_t* ids, int64_t B, int world, int64_t* sorted_local, int64_t* perm, int64_t* pos,
+                     int64_t* counts, int* err_flag, void* workspace, int64_t workspace_bytes, void* stream);
+int rihip_gather_rows(const float* table, int64_t n_rows, const int64_t* ids, int64_t n, int d, float* out,
+                      int* err_flag, void* stream);
+
 /* ---- inner-product index -------------------------------------------------------------------
  * Replaces faiss.IndexFlatIP / IndexIVFFlat(METRIC_INNER_PRODUCT) behind FAISSIndex
  * (src/models/faiss_index.py:68-74 build, :113/:145 search, :164/:196 write/read).

@@ -64,6 +64,9 @@ SIGNATURES = {
     "rihip_rows_reduce": (C.c_int, [vp, c_i64, C.c_int, vp, vp, vp, vp, vp]),
     "rihip_adam_rows": (C.c_int, [vp, vp, vp, vp, vp, c_i64, C.c_int, vp, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.c_float, c_i64, vp, vp, vp]),
+    "rihip_route_workspace_bytes": (c_i64, [c_i64]),
+    "rihip_route_rows": (C.c_int, [vp, c_i64, C.c_int, vp, vp, vp, vp, vp, vp, c_i64, vp]),
+    "rihip_gather_rows": (C.c_int, [vp, c_i64, vp, c_i64, C.c_int, vp, vp, vp]),
     "rihip_ip_index_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
     "rihip_ip_index_destroy": (C.c_int, [vp]),
     "rihip_ip_index_set_vectors": (C.c_int, [vp, vp, c_i64, C.c_int, vp]),

@@ -13,11 +13,16 @@ MLP parameters are always dense (one flat buffer: one grad-norm pass + one Adam 
 Two loss modes: ``sampled`` (one explicit negative per positive -- what the reference trains
 with) and ``inbatch`` (TwoTowerModel.in_batch_bpr_loss, never called by the reference trainer).
 
-Multi-GPU (one process per GPU, torch.distributed/RCCL): user rows are sharded (each rank trains
-pairs whose user row it owns: zero communication for user rows), the item table is replicated and
-kept identical by all-gathering the per-rank (item id, row-gradient) lists; in-batch negatives are
-global through an all-gather of tower outputs; MLP grads are all-reduced; the clip norm is one
-all-reduced scalar.  See DESIGN.md "Multi-GPU".
+Multi-GPU (one process per GPU, torch.distributed/RCCL; opt-in with ``distributed=True``): user rows are sharded
+(each rank trains pairs whose user row it owns: zero communication for user rows).  The item table is either
+  * ``item_shard="replicate"`` -- a full copy per rank, kept identical by all-gathering the per-rank (item id,
+    row-gradient) lists; or
+  * ``item_shard="rows"`` -- cut by rows (global row g on rank (g-1) % W, BASELINE cfg4): per step the batch's item ids
+    are routed to their owners (ids all-to-all), the owners gather the rows and send them back (rows all-to-all), the
+    item tower runs on the received rows, and the row gradients return to the owners (grads all-to-all), who apply the
+    row-sparse Adam to the rows they own.  One host sync per step (the split sizes).
+In-batch negatives are global through an all-gather of the item-tower outputs; MLP grads are all-reduced; the clip norm
+is an all-reduced scalar.  See DESIGN.md "Multi-GPU".
 """
 from __future__ import annotations
 
@@ -30,7 +35,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib as L
-from .dist_utils import all_gather_into, all_reduce_sum_, reduce_scatter_sum
+from .dist_utils import all_gather_into, all_reduce_sum_, all_to_all_rows, exchange_counts, reduce_scatter_sum
 from .two_tower import TwoTowerModel
 
 _MLP_KEYS = ["user_tower.mlp.0.weight", "user_tower.mlp.0.bias", "user_tower.mlp.3.weight", "user_tower.mlp.3.bias",
@@ -99,8 +104,14 @@ class HipBPRTrainer:
     def __init__(self, model: TwoTowerModel, batch_size: int, lr: float = 1e-3, weight_decay: float = 1e-5,
                  betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = 1.0, loss_mode: str = "sampled",
                  table_opt: str = "dense", seed: int = 0, process_group=None, user_row_offset: int = 0,
-                 inbatch_precision: int = 0, use_graph: bool = False, inbatch_store_g=None):
+                 inbatch_precision: int = 0, use_graph: bool = False, inbatch_store_g=None,
+                 distributed: bool = False, item_shard: str = "replicate"):
+        """distributed=True (or a process_group): this trainer is one rank of a collective job -- EVERY rank of the
+        group must construct it and call step() in lock-step.  Default False even when torch.distributed is
+        initialised, so that a single-rank trainer inside a distributed program never issues collectives.
+        item_shard="rows": model.item_tower.embedding holds only this rank's rows of the item table (see module doc)."""
         assert loss_mode in ("sampled", "inbatch") and table_opt in ("dense", "sparse")
+        assert item_shard in ("replicate", "rows")
         self.lib = L.lib()
         self.model = model
         self.dev = L.device()
@@ -118,8 +129,12 @@ class HipBPRTrainer:
         self._side_stream = torch.cuda.Stream(device=self.dev)
         self._eager_steps = 0  # bench hook: list collecting (start, end) events around every sweep launch
         self.pg = process_group
-        self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
-        self.rank = dist.get_rank(process_group) if self.world > 1 else 0
+        self.dist = bool(distributed) or process_group is not None   # collectives are issued iff this is set
+        if self.dist and not dist.is_initialized():
+            raise RuntimeError("HipBPRTrainer(distributed=True) needs torch.distributed.init_process_group first")
+        self.world = dist.get_world_size(process_group) if self.dist else 1
+        self.rank = dist.get_rank(process_group) if self.dist else 0
+        self.item_rows = self.dist and item_shard == "rows"
         self.user_row_offset = int(user_row_offset)  # global id of local user-table row 0 (sharded tables)
         d, H = model.embed_dim, model.hidden_dim
         self.d, self.H = d, H
@@ -148,12 +163,14 @@ class HipBPRTrainer:
         self.utab = model.user_tower.embedding.weight.data
         self.itab = model.item_tower.embedding.weight.data
         nI = self.B * (2 if loss_mode == "sampled" else 1)
-        nI_all = nI * (self.world if self.world > 1 else 1)  # replicated item table sees every rank's rows
+        self.nI = nI
+        # replicated item table: applies every rank's rows; row-sharded: up to every rank's requests can hit one owner
+        nI_all = nI * self.world
         if table_opt == "sparse":
             self.uopt = _RowsOpt(self.utab, self.B)
             self.iopt = _RowsOpt(self.itab, nI_all)
         else:
-            assert self.world == 1, "dense table optimiser is single-GPU (parity mode)"
+            assert not self.dist, "dense table optimiser is single-GPU (parity mode)"
             self.uopt = _DenseOpt(self.utab)
             self.iopt = _DenseOpt(self.itab)
             # host arrays of device pointers for the multi-tensor launches: [MLP flat buffer, user table, item table]
@@ -190,7 +207,7 @@ class HipBPRTrainer:
         self.part = torch.zeros((self.np_mlp + 2 * self.np_rows + 8,), dtype=torch.float64, device=self.dev)
         self.lpart = torch.zeros((max(1024, self.lib.rihip_inbatch_workspace_doubles(B)),), dtype=torch.float64,
                                  device=self.dev)
-        Gall = B * (self.world if self.world > 1 else 1)
+        Gall = B * self.world
         self.sws = torch.empty((max(self.lib.rihip_inbatch_workspace_floats(B, Gall, d),
                                     self.lib.rihip_inbatch_workspace_floats(Gall, B, d)),), **f32)
         self.n_lparts = self.lib.rihip_inbatch_loss_parts(B, Gall)
@@ -207,16 +224,28 @@ class HipBPRTrainer:
             self.inbatch_store_g = bool(store) and self.inbatch_precision in (0, 2)
             if self.inbatch_store_g:
                 self.gmat = torch.empty((ng,), **f32)
-            if self.world > 1:
+            if self.dist:
                 W = self.world
                 self.I_all = torch.empty((W * B, d), **f32)
                 if self.inbatch_store_g:
                     self.dI_all = torch.empty((W * B, d), **f32)
                 self.U_all = None  # recompute form only: allocated on first use
-        if self.world > 1:
+        if self.dist and not self.item_rows:
             W = self.world
             self.iid_all = torch.empty((W * nI,), dtype=torch.int64, device=self.dev)
             self.dXi_all = torch.empty((W * nI, d), **f32)
+        if self.item_rows:
+            # routing state of one step (ids all-to-all -> rows all-to-all -> grads all-to-all), worst-case capacities
+            W = self.world
+            i64 = dict(dtype=torch.int64, device=self.dev)
+            self.rt_ws = torch.empty((self.lib.rihip_route_workspace_bytes(nI),), dtype=torch.uint8, device=self.dev)
+            self.rt_local = torch.empty((nI,), **i64); self.rt_perm = torch.empty((nI,), **i64)
+            self.rt_pos = torch.empty((nI,), **i64); self.rt_counts = torch.empty((W,), **i64)
+            self.req_ids = torch.empty((W * nI,), **i64)            # owner side: local rows requested by all ranks
+            self.rows_out = torch.empty((W * nI, d), **f32)         # owner side: those rows / their gradients
+            self.rows_in = torch.empty((nI, d), **f32)              # requester side: staging table the item tower reads
+            self.dX_sorted = torch.empty((nI, d), **f32)
+            self._n_req = 0
 
     # ------------------------------------------------------------------------------------------
     def _fwd(self, table, ids, genres, keys, out, hid, den, seed):
@@ -254,7 +283,7 @@ class HipBPRTrainer:
             self.lr_dev.fill_(lr)
             self._lr_host = lr
         self.step_count += 1
-        if not (self.use_graph and self.world == 1 and self.sweep_events is None):
+        if not (self.use_graph and not self.dist and self.sweep_events is None):
             return self._step_impl(user_ids, item_ids, item_genres)
         if self._graph is None:
             if self._eager_steps < 1:      # first call eager: warms the library (rocPRIM temp queries, lazy module load)
@@ -278,18 +307,30 @@ class HipBPRTrainer:
         t, lr = 0, 0.0   # the device clock (hyper_dev) overrides the host-side step / lr arguments below
         ukeys, ikeys = _MLP_KEYS[:4], _MLP_KEYS[4:]
         s0 = (self.seed * 1000003 + self.rank * 7919) & ((1 << 62) - 1)   # + device step counter inside the kernel
-        # item tower first: in the multi-GPU in-batch mode its outputs travel (all-gather) under the user tower
-        self._fwd(self.itab, item_ids, item_genres, ikeys, self.I, self.hidI, self.denI, s0 + 1)
         self._I_work = None
-        if self.world > 1 and self.loss_mode == "inbatch":
-            self._I_work = all_gather_into(self.I_all, self.I, self.pg, async_op=True)
-        self._fwd(self.utab, user_ids, None, ukeys, self.U, self.hidU, self.denU, s0)
+        itab, iids = self.itab, item_ids
+        if self.item_rows:
+            # row-sharded item table: the rows travel (all-to-all) under the user tower, then the item tower reads the
+            # received rows as a [nI,d] staging table indexed by each pair's send slot
+            w_rows = self._fetch_item_rows(item_ids, st)
+            self._fwd(self.utab, user_ids, None, ukeys, self.U, self.hidU, self.denU, s0)
+            w_rows.wait()
+            itab, iids = self.rows_in, self.rt_pos
+            self._fwd(itab, iids, item_genres, ikeys, self.I, self.hidI, self.denI, s0 + 1)
+            if self.loss_mode == "inbatch":
+                self._I_work = all_gather_into(self.I_all, self.I, self.pg, async_op=True)
+        else:
+            # item tower first: in the multi-GPU in-batch mode its outputs travel (all-gather) under the user tower
+            self._fwd(self.itab, item_ids, item_genres, ikeys, self.I, self.hidI, self.denI, s0 + 1)
+            if self.dist and self.loss_mode == "inbatch":
+                self._I_work = all_gather_into(self.I_all, self.I, self.pg, async_op=True)
+            self._fwd(self.utab, user_ids, None, ukeys, self.U, self.hidU, self.denU, s0)
 
         if self.loss_mode == "sampled":
             L.check(lib.rihip_bpr_pair_loss(self.U.data_ptr(), self.I.data_ptr(), self.I[B:].data_ptr(), B, d,
                                             self.loss.data_ptr(), self.dU.data_ptr(), self.dI.data_ptr(),
                                             self.dI[B:].data_ptr(), self.lpart.data_ptr(), st), "bpr_pair_loss")
-            if self.world > 1:  # mean over the global batch
+            if self.dist:  # mean over the global batch
                 self.dU.div_(self.world); self.dI.div_(self.world)
                 self.loss.div_(self.world)
                 all_reduce_sum_(self.loss, self.pg)
@@ -300,12 +341,21 @@ class HipBPRTrainer:
         self._bwd(self.utab, user_ids, None, ukeys, self.dU, self.U, self.denU, self.hidU, self.dXu)
         if self._dI_work is not None:
             self._dI_work.wait(); self._dI_work = None
-        self._bwd(self.itab, item_ids, item_genres, ikeys, self.dI, self.I, self.denI, self.hidI, self.dXi)
+        self._bwd(itab, iids, item_genres, ikeys, self.dI, self.I, self.denI, self.hidI, self.dXi)
 
         # ---- gradient exchange (multi-GPU) + global grad norm -> clip coef (device scalar)
         iid, dXi = item_ids, self.dXi
         w_i = w_x = None
-        if self.world > 1:
+        if self.item_rows:
+            # row gradients return to the owners of the rows, in the order the ids went out
+            L.check(lib.rihip_gather_rows(self.dXi.data_ptr(), self.nI, self.rt_perm.data_ptr(), self.nI, d,
+                                          self.dX_sorted.data_ptr(), self.err.data_ptr(), st), "gather_rows")
+            n_req = self._n_req
+            w_x = all_to_all_rows(self.rows_out[:n_req], self.dX_sorted, self._recv_counts, self._send_counts, self.pg,
+                                  async_op=True)
+            all_reduce_sum_(self.flat_g, self.pg)
+            iid, dXi = self.req_ids[:n_req], self.rows_out[:n_req]
+        elif self.dist:
             # the item row gradients travel while the MLP all-reduce and the user-row grouping run
             w_i = all_gather_into(self.iid_all, item_ids, self.pg, async_op=True)
             w_x = all_gather_into(self.dXi_all, self.dXi, self.pg, async_op=True)
@@ -326,21 +376,30 @@ class HipBPRTrainer:
             with torch.cuda.stream(side):
                 self.uopt.group_reduce(user_ids, self.dXu, pp + 8 * o1, side.cuda_stream)
             if w_i is not None:
-                w_i.wait(); w_x.wait()
-            self.iopt.group_reduce(iid, dXi, pp + 8 * o2, st)
+                w_i.wait()
+            if w_x is not None:
+                w_x.wait()
+            if iid.numel() > 0:
+                self.iopt.group_reduce(iid, dXi, pp + 8 * o2, st)
+            else:   # this rank owns none of the rows of the step
+                self.part[o2:o2 + self.np_rows].zero_()
+                self.iopt._B = 0
             cur.wait_stream(side)
         else:
             # dense tables (ML-1M scale): the table gradients were zeroed by the previous step's Adam launch
             self.uopt.scatter(user_ids, self.dXu, st, zero=False)
             self.iopt.scatter(iid, dXi, st, zero=False)
         n_part = o2 + self.np_rows
-        if self.world > 1:
-            # user rows are disjoint across ranks: their squared norms add; MLP and (replicated) item
-            # parts are already global and identical on every rank
-            usq = self.part[o1:o2].sum().reshape(1)
-            all_reduce_sum_(usq, self.pg)
+        if self.dist:
+            # user rows are disjoint across ranks: their squared norms add; the MLP part is already global; the item
+            # part is global when the table is replicated and disjoint (-> added up) when it is row-sharded
+            sq = torch.stack([self.part[o1:o2].sum(), self.part[o2:n_part].sum()])
+            all_reduce_sum_(sq, self.pg)
             self.part[o1:o2].zero_()
-            self.part[o1] = usq[0]
+            self.part[o1] = sq[0]
+            if self.item_rows:
+                self.part[o2:n_part].zero_()
+                self.part[o2] = sq[1]
         if dense:   # one launch for the three squared norms (MLP, user table, item table gradients)
             L.check(lib.rihip_sumsq_multi(3, self._mt_g, self._mt_n, pp, st), "sumsq_multi")
         L.check(lib.rihip_clip_coef(pp, n_part, self.max_norm, self.coef.data_ptr(), self.gnorm.data_ptr(), st),
@@ -355,8 +414,25 @@ class HipBPRTrainer:
                                      self.flat_v.data_ptr(), self.flat_p.numel(), lr, self.b1, self.b2, self.eps,
                                      self.wd, t, cp, hp, st), "adam_dense")
         self.uopt.adam(lr, self.b1, self.b2, self.eps, self.wd, t, cp, st, hp)
-        self.iopt.adam(lr, self.b1, self.b2, self.eps, self.wd, t, cp, st, hp)
+        if self.iopt._B > 0:
+            self.iopt.adam(lr, self.b1, self.b2, self.eps, self.wd, t, cp, st, hp)
         return self.loss
+
+    def _fetch_item_rows(self, item_ids: torch.Tensor, st: int):
+        """Row-sharded item table, forward half of the exchange: route the step's global item ids to their owners,
+        all-to-all the owner-local row numbers, gather the requested rows here, all-to-all them back (async handle).
+        Leaves: rt_pos (send slot of each pair = its row in rows_in), rt_perm, req_ids[:n_req], the split lists."""
+        lib, d, nI = self.lib, self.d, self.nI
+        L.check(lib.rihip_route_rows(item_ids.data_ptr(), nI, self.world, self.rt_local.data_ptr(),
+                                     self.rt_perm.data_ptr(), self.rt_pos.data_ptr(), self.rt_counts.data_ptr(),
+                                     self.err.data_ptr(), self.rt_ws.data_ptr(), self.rt_ws.numel(), st), "route_rows")
+        self._send_counts, self._recv_counts = exchange_counts(self.rt_counts, self.pg)   # the step's one host sync
+        n_req = self._n_req = int(sum(self._recv_counts))
+        all_to_all_rows(self.req_ids[:n_req], self.rt_local, self._recv_counts, self._send_counts, self.pg)
+        L.check(lib.rihip_gather_rows(self.itab.data_ptr(), self.itab.shape[0], self.req_ids.data_ptr(), n_req, d,
+                                      self.rows_out.data_ptr(), self.err.data_ptr(), st), "gather_rows")
+        return all_to_all_rows(self.rows_in, self.rows_out[:n_req], self._send_counts, self._recv_counts, self.pg,
+                               async_op=True)
 
     def _timed(self, fn, what, *args) -> None:
         ev = self.sweep_events
@@ -376,7 +452,7 @@ class HipBPRTrainer:
         G, off = W * B, self.rank * B
         L.check(lib.rihip_rowdot(self.U.data_ptr(), self.I.data_ptr(), B, 0, d, self.pos.data_ptr(), st), "rowdot")
         I_all = self.I
-        if W > 1:
+        if self.dist:
             # global in-batch negatives: every rank scores its users against ALL items (4 MiB/rank at B=8192, d=128);
             # the all-gather was started right after the item tower's forward
             self._I_work.wait()
@@ -387,12 +463,12 @@ class HipBPRTrainer:
             self._timed(lib.rihip_inbatch_user_pass, "inbatch_user_pass", self.U.data_ptr(), B, off, I_all.data_ptr(),
                         G, 0, d, self.pos.data_ptr(), G, self.dU.data_ptr(), self.r.data_ptr(), self.lpart.data_ptr(),
                         self.sws.data_ptr(), self.gmat.data_ptr(), self.inbatch_precision, st)
-            dI_all = self.dI if W == 1 else self.dI_all
+            dI_all = self.dI if not self.dist else self.dI_all
             self._timed(lib.rihip_inbatch_item_pass, "inbatch_item_pass", self.gmat.data_ptr(), self.U.data_ptr(), B,
                         off, G, 0, d, self.r.data_ptr(), G, dI_all.data_ptr(), self.sws.data_ptr(), self.inbatch_precision, st)
-            if W > 1:
+            if self.dist:
                 self._dI_work = reduce_scatter_sum(self.dI, self.dI_all, self.pg, async_op=True)
-        elif W == 1:
+        elif not self.dist:
             self._sweep(1, self.U.data_ptr(), B, 0, self.I.data_ptr(), B, 0, d,
                                             self.pos.data_ptr(), None, B, self.dU.data_ptr(), self.r.data_ptr(),
                                             self.lpart.data_ptr(), self.sws.data_ptr(), self.inbatch_precision, st)
@@ -418,7 +494,7 @@ class HipBPRTrainer:
                                             None, self.sws.data_ptr(), self.inbatch_precision, st)
         L.check(lib.rihip_sum_partials(self.lpart.data_ptr(), self.n_lparts, 1.0 / (G * (G - 1.0)),
                                        self.loss.data_ptr(), st), "sum_partials")
-        if W > 1:
+        if self.dist:
             all_reduce_sum_(self.loss, self.pg)
 
 

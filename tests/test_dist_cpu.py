@@ -64,3 +64,55 @@ def test_two_rank_inbatch_decomposition(tmp_path):
         assert abs(float(p["sq"][0]) - float((dU.astype(np.float64) ** 2).sum())) < 1e-12
     np.testing.assert_allclose(np.concatenate([p["dU"] for p in parts]), dU, atol=1e-9)
     np.testing.assert_allclose(np.concatenate([p["dI"] for p in parts]), dI, atol=1e-9)
+
+
+def _route_np(ids, W):
+    """NumPy restatement of rihip_route_rows (csrc/shard.hip): stable sort of the requests by owner rank"""
+    owner = (ids - 1) % W
+    perm = np.argsort(owner, kind="stable")
+    pos = np.empty_like(perm); pos[perm] = np.arange(len(ids))
+    return (ids[perm] - 1) // W + 1, perm, pos, np.bincount(owner, minlength=W).astype(np.int64)
+
+
+def _shard_worker(rank, world, port, nI, n_items, d, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from recommendit_amd.dist_utils import all_to_all_rows, exchange_counts, n_local_rows, shard_rows
+    rng = np.random.RandomState(5)
+    full = rng.randn(n_items + 1, d).astype(np.float32)
+    mine = shard_rows(full, rank, world)
+    assert mine.shape[0] == n_local_rows(n_items, rank, world) + 1
+    ids = np.random.RandomState(10 + rank).zipf(1.3, nI).clip(1, n_items).astype(np.int64)   # skewed, repeated ids
+    local, perm, pos, counts = _route_np(ids, world)
+    send, recv = exchange_counts(torch.from_numpy(counts))
+    assert send == counts.tolist()
+    n_req = sum(recv)
+    req = torch.empty((n_req,), dtype=torch.int64)
+    all_to_all_rows(req, torch.from_numpy(local), recv, send)
+    rows_out = torch.from_numpy(mine[req.numpy()])                       # owner-side gather
+    rows_in = torch.empty((nI, d))
+    all_to_all_rows(rows_in, rows_out, send, recv, async_op=True).wait()
+    np.testing.assert_array_equal(rows_in.numpy()[pos], full[ids])        # every pair got ITS row
+    # gradients travel back in send order; the owner sums duplicates
+    dX = np.random.RandomState(20 + rank).randn(nI, d).astype(np.float32)
+    g_in = torch.empty((n_req, d))
+    all_to_all_rows(g_in, torch.from_numpy(dX[perm]), recv, send)
+    acc = np.zeros_like(mine, dtype=np.float64)
+    np.add.at(acc, req.numpy(), g_in.numpy().astype(np.float64))
+    np.savez(os.path.join(out_dir, f"s{rank}.npz"), acc=acc, ids=ids, dX=dX)
+    dist.destroy_process_group()
+
+
+def test_two_rank_row_sharded_exchange(tmp_path):
+    """ids all-to-all -> rows all-to-all -> grads all-to-all (HipBPRTrainer item_shard="rows") against the
+    single-table scatter-add"""
+    world, nI, n_items, d = 2, 50, 37, 8
+    mp.spawn(_shard_worker, args=(world, _free_port(), nI, n_items, d, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(tmp_path / f"s{r}.npz") for r in range(world)]
+    ref = np.zeros((n_items + 1, d), dtype=np.float64)
+    for p in parts:
+        np.add.at(ref, p["ids"], p["dX"].astype(np.float64))
+    for r, p in enumerate(parts):
+        np.testing.assert_allclose(p["acc"][1:], ref[1 + r::world], atol=1e-12)
+        assert (p["acc"][0] == 0).all()

@@ -1,6 +1,8 @@
 """GPU, 2 ranks sharing one card (gloo staging of the collectives): the sharded HipBPRTrainer
-reproduces the single-process step -- same loss, same replicated item table / MLPs, user shards equal
-to the corresponding rows of the single-process table."""
+reproduces the single-process step -- same loss, same MLPs, user shards equal to the corresponding rows of the
+single-process table, and the item table either replicated (identical on both ranks) or row-sharded
+(rank r holds global rows r+1, r+1+W, ...: ids/rows/grads all-to-alls).  A third test runs the distributed code path
+through RCCL itself with a world of one rank (the only RCCL run a one-GPU box allows)."""
 import os
 import socket
 
@@ -59,7 +61,7 @@ def _fix_batches(batches, shard):
     return out
 
 
-def _worker(rank, world, port, mode, out_dir):
+def _worker(rank, world, port, mode, out_dir, item_shard="replicate"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -73,19 +75,25 @@ def _worker(rank, world, port, mode, out_dir):
     ut = sd["user_tower.embedding.weight"]
     loc["user_tower.embedding.weight"] = torch.from_numpy(
         np.concatenate([ut[:1], ut[1 + rank * shard:1 + (rank + 1) * shard]]).copy())
+    if item_shard == "rows":
+        from recommendit_amd.dist_utils import shard_rows
+        it_local = shard_rows(sd["item_tower.embedding.weight"], rank, world)
+        m = TwoTowerModel(shard, it_local.shape[0] - 1, embed_dim=D, hidden_dim=H, dropout=0.0)
+        loc["item_tower.embedding.weight"] = torch.from_numpy(it_local.copy())
     m.load_state_dict(loc)
     m.train()
-    tr = HipBPRTrainer(m, B, lr=5e-3, loss_mode=mode, table_opt="sparse")
+    tr = HipBPRTrainer(m, B, lr=5e-3, loss_mode=mode, table_opt="sparse", distributed=True, item_shard=item_shard)
     losses = _run_steps(m, tr, _fix_batches(_batches(mode), shard), mode, rank, world, shard)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), losses=np.array(losses),
              **{k: v.detach().cpu().numpy() for k, v in m.named_parameters()})
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("item_shard", ["replicate", "rows"])
 @pytest.mark.parametrize("mode", ["inbatch", "sampled"])
-def test_two_rank_trainer_matches_single_process(tmp_path, mode):
+def test_two_rank_trainer_matches_single_process(tmp_path, mode, item_shard):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path), item_shard), nprocs=world, join=True)
     from recommendit_amd import TwoTowerModel
     from recommendit_amd.trainer import HipBPRTrainer
     sd = _state()
@@ -102,5 +110,77 @@ def test_two_rank_trainer_matches_single_process(tmp_path, mode):
         for k in ref:
             if k == "user_tower.embedding.weight":
                 np.testing.assert_allclose(p[k][1:], ref[k][1 + r * shard:1 + (r + 1) * shard], atol=3e-5, err_msg=k)
+            elif k == "item_tower.embedding.weight" and item_shard == "rows":
+                np.testing.assert_allclose(p[k][1:], ref[k][1 + r::world], atol=3e-5, err_msg=k)
             else:
                 np.testing.assert_allclose(p[k], ref[k], atol=3e-5, err_msg=k)  # Adam amplifies ulp-level grad differences of near-zero grads
+
+
+def _nccl_world1_worker(rank, port, out_dir):
+    """FRESH process: the RCCL group is created before any other GPU work, then the distributed code path (async
+    all-gather / reduce-scatter handles, all-to-alls, stream ordering against the ctypes kernels) runs with W = 1."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from recommendit_amd import TwoTowerModel
+    from recommendit_amd.trainer import HipBPRTrainer
+    out = {}
+    for mode in ("inbatch", "sampled"):
+        for tag, kw in (("plain", {}), ("dist", dict(distributed=True)), ("rows", dict(distributed=True, item_shard="rows"))):
+            sd = _state()
+            m = TwoTowerModel(NU, NI, embed_dim=D, hidden_dim=H, dropout=0.1)
+            m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+            m.train()
+            tr = HipBPRTrainer(m, 2 * B, lr=5e-3, loss_mode=mode, table_opt="sparse", seed=3, **kw)
+            losses = _run_steps(m, tr, _batches(mode), mode, 0, 1, NU)
+            torch.cuda.synchronize()
+            out[f"{mode}_{tag}_loss"] = np.array(losses)
+            for k, v in m.named_parameters():
+                out[f"{mode}_{tag}_{k}"] = v.detach().cpu().numpy()
+    np.savez(os.path.join(out_dir, "w1.npz"), **out)
+    dist.destroy_process_group()
+
+
+def test_rccl_world1_distributed_path_is_bitwise_the_plain_step(tmp_path):
+    """RCCL (backend "nccl") with one rank: all_gather_into_tensor / reduce_scatter_tensor async handles, the
+    all_to_all_single exchange of the row-sharded item table and their ordering against kernels launched through
+    ctypes on torch's current and side streams.  With W = 1 every collective is the identity, so the distributed step
+    must equal the non-distributed one bit for bit (dropout on: same counter-based masks)."""
+    mp.spawn(_nccl_world1_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    r = np.load(tmp_path / "w1.npz")
+    for mode in ("inbatch", "sampled"):
+        keys = [k[len(mode) + 7:] for k in r.files if k.startswith(f"{mode}_plain_")]
+        assert len(keys) == 11
+        for tag in ("dist", "rows"):
+            for k in keys:
+                np.testing.assert_array_equal(r[f"{mode}_{tag}_{k}"], r[f"{mode}_plain_{k}"], err_msg=f"{mode} {tag} {k}")
+
+
+def test_route_rows_and_gather_kernels_vs_numpy():
+    """csrc/shard.hip against the NumPy restatement used by tests/test_dist_cpu.py (stable sort by owner rank)"""
+    from recommendit_amd import _lib as L
+    lib, dev, st = L.lib(), L.device(), L.stream_ptr()
+    rng = np.random.RandomState(3)
+    for B, W, n in ((40, 2, 90), (8192, 8, 10_000_000), (1000, 5, 7), (16384, 1, 1000)):
+        ids = rng.zipf(1.2, B).clip(1, n).astype(np.int64)
+        i64 = dict(dtype=torch.int64, device=dev)
+        idd = torch.from_numpy(ids).to(dev)
+        loc, perm, pos, cnt = (torch.empty(B, **i64), torch.empty(B, **i64), torch.empty(B, **i64), torch.empty(W, **i64))
+        ws = torch.empty(lib.rihip_route_workspace_bytes(B), dtype=torch.uint8, device=dev)
+        err = torch.zeros(1, dtype=torch.int32, device=dev)
+        L.check(lib.rihip_route_rows(idd.data_ptr(), B, W, loc.data_ptr(), perm.data_ptr(), pos.data_ptr(), cnt.data_ptr(),
+                                     err.data_ptr(), ws.data_ptr(), ws.numel(), st), "route_rows")
+        owner = (ids - 1) % W
+        p = np.argsort(owner, kind="stable")
+        np.testing.assert_array_equal(perm.cpu().numpy(), p)
+        np.testing.assert_array_equal(loc.cpu().numpy(), (ids[p] - 1) // W + 1)
+        np.testing.assert_array_equal(pos.cpu().numpy()[p], np.arange(B))
+        np.testing.assert_array_equal(cnt.cpu().numpy(), np.bincount(owner, minlength=W))
+        assert err.item() == 0
+        tab = torch.randn(257, 64, device=dev)
+        gi = torch.from_numpy(rng.randint(0, 257, B)).to(dev)
+        out = torch.empty(B, 64, device=dev)
+        L.check(lib.rihip_gather_rows(tab.data_ptr(), 257, gi.data_ptr(), B, 64, out.data_ptr(), err.data_ptr(), st), "gather")
+        assert torch.equal(out, tab[gi]) and err.item() == 0

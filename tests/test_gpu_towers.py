@@ -252,6 +252,47 @@ def test_inbatch_stored_g_rectangular_rank_form(Bl, G, off, d, prec):
     np.testing.assert_allclose(dI.cpu().numpy(), dIo, atol=3e-9, rtol=3e-4)
 
 
+def test_inbatch_cfg4_per_rank_shape():
+    """BASELINE.json configs[3] as ONE rank of eight sees it: 8 192 local users (positives = items off..off+8191 of
+    the gathered batch) against all 65 536 all-gathered items, d = 128; the item pass returns this rank's partial dI
+    for ALL items (what is reduce-scattered).  Oracle on slices: the first 64 local users against the rectangular
+    closed form; 32 items inside and 32 outside the rank's own block against an fp64 G^T.U over the local users."""
+    from recommendit_amd import _lib as L
+    lib, dev, st = L.lib(), L.device(), L.stream_ptr()
+    Bl, G, d, rank = 8192, 65536, 128, 3
+    off = rank * Bl
+    rng = np.random.RandomState(44)
+    U, I = fx.unit_rows(rng, Bl, d), fx.unit_rows(rng, G, d)
+    Ud, Id = t(U).to(dev).contiguous(), t(I).to(dev).contiguous()
+    f32 = dict(dtype=torch.float32, device=dev)
+    pos = torch.empty(Bl, **f32); r = torch.empty(Bl, **f32)
+    dU = torch.empty(Bl, d, **f32); dI = torch.full((G, d), float("nan"), **f32)
+    lp = torch.zeros(max(1024, lib.rihip_inbatch_workspace_doubles(Bl)), dtype=torch.float64, device=dev)
+    ws = torch.empty(max(lib.rihip_inbatch_workspace_floats(Bl, G, d), lib.rihip_inbatch_workspace_floats(G, Bl, d)), **f32)
+    gm = torch.empty((lib.rihip_inbatch_gmat_floats(Bl, G),), **f32)
+    L.check(lib.rihip_rowdot(Ud.data_ptr(), Id.data_ptr(), Bl, off, d, pos.data_ptr(), st), "rowdot")
+    L.check(lib.rihip_inbatch_user_pass(Ud.data_ptr(), Bl, off, Id.data_ptr(), G, 0, d, pos.data_ptr(), G,
+                                        dU.data_ptr(), r.data_ptr(), lp.data_ptr(), ws.data_ptr(), gm.data_ptr(), 0, st), "up")
+    L.check(lib.rihip_inbatch_item_pass(gm.data_ptr(), Ud.data_ptr(), Bl, off, G, 0, d, r.data_ptr(), G, dI.data_ptr(),
+                                        ws.data_ptr(), 0, st), "ip")
+    assert torch.isfinite(dI).all()
+    _, dUo, _ = O.in_batch_bpr_loss(U[:64], I, owner_offset=off, n_global=G)
+    np.testing.assert_allclose(dU[:64].cpu().numpy(), dUo, atol=1e-12, rtol=5e-4)
+    U64 = U.astype(np.float64)
+    posn = (U64 * I[off:off + Bl].astype(np.float64)).sum(1)[:, None]
+    cols = np.concatenate([np.arange(off + 100, off + 132), np.arange(5, 37)])     # own block / another rank's items
+    S = U64 @ I[cols].astype(np.float64).T
+    Gm = 1.0 / (1.0 + np.exp(-(S - posn))) / (G * (G - 1.0))
+    Gm[np.arange(100, 132), np.arange(32)] = 0.0                                  # the positives of users 100..131
+    dI_off = Gm.T @ U64
+    got = dI[t(cols).to(dev)].double().cpu().numpy()
+    np.testing.assert_allclose(got[32:], dI_off[32:], atol=2e-11, rtol=5e-4)        # no diagonal term off-block
+    res = got[:32] - dI_off[:32]                                                   # own block: -r_j u_j, r_j > 0
+    coef = (res * U[100:132]).sum(1)
+    assert (coef < 0).all()
+    np.testing.assert_allclose(res, coef[:, None] * U[100:132], atol=2e-10, rtol=0)
+
+
 def test_inbatch_unnormalised_inputs_keep_the_limits():
     """The element works in the log2 domain with sigma = 1/(1+2^-z2) and one log per 8 factors of (1+e^-z): rows of
     norm 2 (|z| up to 8) must still match the oracle, and saturated scores (|z| ~ 200) must give finite gradients
