@@ -1,24 +1,34 @@
 #!/usr/bin/env python3
-"""bench.py -- BPR pairs/sec (+ top-500 IP queries/sec) of the MI355X hot path.
+"""bench.py -- BPR pairs/sec (+ top-500 IP queries/sec, end-to-end serve) of the MI355X hot path.
 
     python bench.py --gpus N --steps K --warmup W           (N=1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json north_star: "synthetic 10M-user x 1M-item d=128"): one step = one pass of
-the Two-Tower BPR training path (towers fwd -> in-batch-negative BPR -> towers bwd -> global
-clip-norm -> Adam on MLPs + row-sparse Adam on touched embedding rows) over a GLOBAL batch of 65 536
-synthetic pairs with global in-batch negatives.  Strong scaling: tables and global batch are fixed;
-N ranks shard the user rows and the batch (8 192 pairs per rank at N=8, the cfg-4 shape), the item
-table is replicated, in-batch negatives stay global through RCCL all-gathers of the tower outputs.
-Inputs (ids, genres, tables) are resident in HBM before the timed region.
+Headline (BASELINE.json north_star): one step = one pass of the Two-Tower BPR training path (towers fwd ->
+in-batch-negative BPR -> towers bwd -> global clip-norm -> Adam on MLPs + row-sparse Adam on touched embedding rows)
+over a GLOBAL batch of 65 536 synthetic pairs with global in-batch negatives.  STRONG scaling: tables and the global
+batch are fixed, N ranks shard the user rows and the batch (8 192 pairs per rank at N=8), in-batch negatives stay global
+through an RCCL all-gather of the item-tower outputs; per-pair work (6 x 65 536 x 128 FLOP of score matrix) is the same
+at every N.
 
-Extra objects on the JSON line: `roofline` (dominant kernel = in-batch sweep, exact-f32 MFMA bound),
-`cpu_baseline` (NumPy oracle on host cores, bounded sample), `secondary` (sampled-negative pairs/s --
-the mode the reference actually trains in -- and top-500 brute-force IP queries/s with its own roofline).
+  --config cfg3 (default for N < 8): BASELINE configs[2] tables, 10M users x 1M items; item table replicated.
+  --config cfg4 (default for N = 8): BASELINE configs[3] tables, 100M users x 10M items, BOTH tables row-sharded (item
+            rows travel by ids/rows/grads all-to-alls), B_local = 8 192.  Fits one GPU too (169 GB of tables+moments).
+
+Inputs (ids, genres, tables) are resident in HBM before the timed region.  Embedding rows are drawn U(-2, 2)
+(trained-scale rows; Xavier over 10M rows gives +-0.0008, every tower output collapses onto the bias direction and
+the loss sits at ln 2 -- degenerate operands for a power-limited chip).
+
+Extra objects on the JSON line: `roofline` (dominant kernel = in-batch user pass, exact-f32 MFMA bound), `cpu_baseline`
+(stock torch-CPU f32 restatement of the same step on the host cores, bounded sample), `secondary` (each leg with its
+own `roofline` and `cpu_baseline`): split-bf16 modes of the same step, the sampled-negative step (the mode the
+reference trains in), the ML-1M-shaped configs[0]/[1] steps, top-500 brute-force IP retrieval on two query
+distributions, and the cfg5 serve chain.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -31,9 +41,18 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-N_USERS, N_ITEMS, D, H = 10_000_000, 1_000_000, 128, 128
+PEAK_BF16_MFMA_TFLOPS = 2500.0
+PEAK_HBM_BYTES = 8.0e12
+D, H = 128, 128
 GLOBAL_BATCH = 65536
 K_TOP = 500
+CONFIGS = {
+    "cfg3": dict(users=10_000_000, items=1_000_000, item_shard="replicate",
+                 name="BASELINE configs[2] tables: synthetic 10M users x 1M items"),
+    "cfg4": dict(users=100_000_000, items=10_000_000, item_shard="rows",
+                 name="BASELINE configs[3] tables: synthetic 100M users x 10M items"),
+}
+INIT_HALF_WIDTH = 2.0
 
 
 def log(*a):
@@ -41,10 +60,18 @@ def log(*a):
         print(*a, file=sys.stderr, flush=True)
 
 
-def make_model(n_users_local, n_items, d, hidden, seed):
+def make_model(n_users_local, n_items_local, d, hidden, seed, user_seed, item_seed):
+    """MLPs from `seed`; tables re-drawn U(-w, w) (rank-specific seeds for shards) so that tower outputs are not
+    degenerate.  Replicas are made identical across ranks by an explicit broadcast in build_trainer."""
     from recommendit_amd import TwoTowerModel
     torch.manual_seed(seed)
-    m = TwoTowerModel(n_users_local, n_items, embed_dim=d, hidden_dim=hidden, dropout=0.1)
+    m = TwoTowerModel(n_users_local, n_items_local, embed_dim=d, hidden_dim=hidden, dropout=0.1)
+    dev = m.user_tower.embedding.weight.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(item_seed)
+    m.item_tower.embedding.weight.data.uniform_(-INIT_HALF_WIDTH, INIT_HALF_WIDTH, generator=g)
+    g.manual_seed(user_seed)
+    m.user_tower.embedding.weight.data.uniform_(-INIT_HALF_WIDTH, INIT_HALF_WIDTH, generator=g)
     m.train()
     return m
 
@@ -53,7 +80,6 @@ def zipf_ids(n, n_items, a, gen, device):
     """item ids ~ Zipf(a) over [1, n_items] by inverse-CDF of the continuous approximation (popularity skew
     stresses the row-gradient grouping)."""
     u = torch.rand((n,), device=device, generator=gen, dtype=torch.float64)
-    # P(X <= x) ~ (x^(1-a) - 1) / (N^(1-a) - 1)
     x = (1.0 + u * (float(n_items) ** (1.0 - a) - 1.0)) ** (1.0 / (1.0 - a))
     return x.floor().clamp_(1, n_items).to(torch.int64)
 
@@ -89,41 +115,349 @@ def timed(fn, n, world):
     return dt
 
 
-def cpu_baseline_inbatch(seconds_budget=25.0):
-    """NumPy oracle on the host cores, bounded sample of the SAME workload: a block of 512 users (and their 512
-    positive items) of one global step against all 65 536 in-batch items: towers fwd+bwd for the block's rows +
-    in-batch loss/gradients (the rectangular form of two_tower.py:132-160).  Same work per pair as the GPU run."""
-    from oracle import fixtures as fx
-    from oracle import two_tower_np as O
+def git_head():
     try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        return subprocess.run(["git", "-C", str(ROOT), "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                              timeout=5).stdout.strip() or None
     except Exception:
-        cores = os.cpu_count() or 1
-    blk, G = 512, GLOBAL_BATCH
-    sd = fx.make_state(4096, 4096, D, H, seed=1)
-    rng = np.random.RandomState(0)
-    I_all = fx.unit_rows(rng, G, D)
-    pu = O.TowerParams(sd["user_tower.embedding.weight"], sd["user_tower.mlp.0.weight"], sd["user_tower.mlp.0.bias"],
-                       sd["user_tower.mlp.3.weight"], sd["user_tower.mlp.3.bias"])
-    pi = O.TowerParams(sd["item_tower.embedding.weight"], sd["item_tower.mlp.0.weight"], sd["item_tower.mlp.0.bias"],
-                       sd["item_tower.mlp.3.weight"], sd["item_tower.mlp.3.bias"])
-    n_done, t0 = 0, time.perf_counter()
-    while True:
-        u, p, gp, _, _ = fx.make_batch(4096, 4096, blk, seed=n_done, boundary=False)
-        U, cu = O.tower_forward(pu, u)
-        P, cp = O.tower_forward(pi, p, gp)
-        I_all[:blk] = P
-        _, dU, dI = O.in_batch_bpr_loss(U, I_all, owner_offset=0, n_global=G)
-        O.tower_backward(pu, cu, dU)
-        O.tower_backward(pi, cp, dI[:blk])
-        n_done += blk
-        if time.perf_counter() - t0 > seconds_budget or n_done >= 32 * blk:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": n_done / dt, "unit": "pairs/s", "cores": int(cores), "kind": "port",
-            "sample": f"{n_done} pairs = {n_done // blk} blocks of {blk} users x all {G} in-batch items of one step "
-                      f"(towers fwd+bwd + in-batch loss/grads, NumPy oracle, float64 score block), {dt:.1f}s"}
+        return None
+
+
+def load_traffic():
+    """HBM bytes per launch from the rocprofv3 --pmc passes of tools/profile_round.sh (FETCH_SIZE doubled as the guide
+    prescribes for wide coalesced reads + WRITE_SIZE).  A static table measured on an earlier commit, NOT in this run:
+    the source commit travels with the number."""
+    tf = ROOT / "profiles" / "traffic.json"
+    if tf.exists():
+        try:
+            return json.loads(tf.read_text())
+        except Exception:
+            pass
+    return {}
+
+
+def event_means(ev):
+    by = {}
+    for what, e0, e1 in ev:
+        by.setdefault(what, []).append(e0.elapsed_time(e1))
+    return {k: sum(v) / len(v) for k, v in by.items()}
+
+
+def run_inbatch(tr, batches, W, K, world, precision):
+    tr.inbatch_precision = precision
+
+    def step(i):
+        u, it, g = batches[i % len(batches)]
+        tr.step(u, it, g)
+
+    for i in range(W):
+        step(i)
+    ev = []
+    tr.sweep_events = ev          # per-launch HIP events on the launch stream, inside the timed region
+    dt = timed(lambda i: step(W + i), K, world)
+    tr.sweep_events = None
+    return dt, event_means(ev), float(tr.loss.item())
+
+
+def build_trainer(cfg, world, rank, B, loss_mode, seed):
+    from recommendit_amd.dist_utils import broadcast_, n_local_rows
+    from recommendit_amd.trainer import HipBPRTrainer
+    n_users_local = cfg["users"] // world
+    rows = cfg["item_shard"] == "rows" and world > 1
+    n_items_local = n_local_rows(cfg["items"], rank, world) if rows else cfg["items"]
+    model = make_model(n_users_local, n_items_local, D, H, seed=1234, user_seed=1000 + rank,
+                       item_seed=2000 + (rank if rows else 0))
+    tr = HipBPRTrainer(model, B, lr=1e-3, weight_decay=1e-5, loss_mode=loss_mode, table_opt="sparse", seed=seed,
+                       distributed=world > 1, item_shard="rows" if rows else "replicate")
+    if world > 1:   # replicated state starts bit-identical on every rank: MLPs always, the item table when replicated
+        broadcast_(tr.flat_p, 0)
+        if not rows:
+            broadcast_(tr.itab, 0)
+    return model, tr, n_users_local
+
+
+def headline(cfg_name, args, world, rank, dev, want_modes):
+    cfg = CONFIGS[cfg_name]
+    G = args.global_batch
+    B = G // world
+    K, W = args.steps, args.warmup
+    model, tr, n_users_local = build_trainer(cfg, world, rank, B, "inbatch", seed=rank)
+    batches = make_batches(W + K, B, n_users_local, cfg["items"], dev, seed=7 + rank, sampled=False)
+    dt, mean_ms, loss = run_inbatch(tr, batches, W, K, world, 0)
+    pairs_per_s = G * K / dt
+    traffic = load_traffic()
+    bgd = float(B) * G * D
+    if "inbatch_user_pass" in mean_ms:
+        # stored-G form: the user pass computes the scores once (2BGd) and dU (2BGd) and writes G; the item pass is
+        # dI = G^T.U (2BGd).  Executed = algorithmic = 6*B_neg*d per pair (SURVEY §8d).
+        t_launch, t_item = mean_ms["inbatch_user_pass"] / 1e3, mean_ms["inbatch_item_pass"] / 1e3
+        flop_launch = 4.0 * bgd
+        achieved = flop_launch / t_launch / 1e12
+        roofline = {"bound": "mfma", "kernel": "inbatch_sweep_kernel<128,user,store-G>", "achieved": achieved,
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                    "traffic": traffic.get(f"inbatch_user_pass_n{world}"),
+                    "traffic_source": traffic.get("_source", "profiles/traffic.json (static PMC table, not this run)"),
+                    "launch_ms": t_launch * 1e3, "algorithmic_flop_per_launch": flop_launch,
+                    "executed_flop_per_launch": flop_launch,
+                    "second_kernel": {"kernel": "inbatch_gt_kernel<128>", "launch_ms": t_item * 1e3,
+                                      "algorithmic_flop_per_launch": 2.0 * bgd, "achieved": 2.0 * bgd / t_item / 1e12,
+                                      "frac": 2.0 * bgd / t_item / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                      "traffic": traffic.get(f"inbatch_item_pass_n{world}")},
+                    "loss_stage_algorithmic_tflops": 6.0 * bgd / (t_launch + t_item) / 1e12}
+        log(f"[bench] {cfg_name} in-batch: {pairs_per_s:,.0f} pairs/s, {dt / K * 1e3:.2f} ms/step, loss {loss:.4f}, "
+            f"user pass {t_launch * 1e3:.3f} ms = {achieved:.1f} TFLOP/s, item pass {t_item * 1e3:.3f} ms = "
+            f"{2.0 * bgd / t_item / 1e12:.1f} TFLOP/s")
+    else:
+        t_launch = mean_ms.get("inbatch_sweep", 0.0) / 1e3
+        flop_launch = 3.0 * bgd                       # algorithmic: 6*B_neg*d per pair (SURVEY §8d) / 2 launches
+        achieved = flop_launch / t_launch / 1e12 if t_launch > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "inbatch_sweep_kernel<128>", "achieved": achieved,
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                    "traffic": traffic.get(f"inbatch_sweep_n{world}"), "launch_ms": t_launch * 1e3,
+                    "algorithmic_flop_per_launch": flop_launch, "executed_flop_per_launch": 4.0 * bgd}
+        log(f"[bench] {cfg_name} in-batch: {pairs_per_s:,.0f} pairs/s, {dt / K * 1e3:.2f} ms/step, loss {loss:.4f}, "
+            f"sweep {t_launch * 1e3:.3f} ms/launch = {achieved:.1f} TFLOP/s algorithmic")
+    modes = {}
+    if want_modes:
+        # same step, stored-G passes on split-bf16 MFMA with fp32-level accuracy ("bf16x6": exact 3-way operand split, 6
+        # partial products; same test tolerances) and the two-piece "bf16x3" sweep
+        dt6, m6, l6 = run_inbatch(tr, batches, W, K, world, 2)
+        tu6, ti6 = m6.get("inbatch_user_pass", 0.0) / 1e3, m6.get("inbatch_item_pass", 0.0) / 1e3
+        modes["inbatch_bf16x6"] = {
+            "metric": "bpr_pairs_per_sec", "value": G * K / dt6, "unit": "pairs/s", "ms_per_step": dt6 / K * 1e3,
+            "dtype": "bf16x6: fp32 operands split exactly into 3 bf16 pieces, 6 of 9 partial products on bf16 MFMA, "
+                     "f32 accumulate (dropped terms <= 2^-23 |a||b|)",
+            "user_pass_ms": tu6 * 1e3, "item_pass_ms": ti6 * 1e3, "final_loss": l6,
+            "roofline": {"bound": "mfma", "kernel": "inbatch_x6_user_kernel", "unit": "TFLOP/s",
+                         "achieved": 24.0 * bgd / tu6 / 1e12 if tu6 > 0 else 0.0, "peak": PEAK_BF16_MFMA_TFLOPS,
+                         "frac": 24.0 * bgd / tu6 / 1e12 / PEAK_BF16_MFMA_TFLOPS if tu6 > 0 else 0.0,
+                         "note": "executed bf16 MFMA FLOP (6 partial products); algorithmic = 1/6 of it"},
+            "note": "optional precision mode (HipBPRTrainer(inbatch_precision=2)); held to the SAME tolerances as the "
+                    "f32-MFMA path in tests/test_gpu_towers.py; the chip runs it power-limited at ~1.8 GHz"}
+        log(f"[bench] in-batch bf16x6: {G * K / dt6:,.0f} pairs/s, {dt6 / K * 1e3:.2f} ms/step, user pass "
+            f"{tu6 * 1e3:.3f} ms, item pass {ti6 * 1e3:.3f} ms")
+        dtb, mb, lb = run_inbatch(tr, batches, W, K, world, 1)
+        tl2 = mb.get("inbatch_sweep", 0.0) / 1e3
+        modes["inbatch_bf16x3"] = {
+            "metric": "bpr_pairs_per_sec", "value": G * K / dtb, "unit": "pairs/s", "ms_per_step": dtb / K * 1e3,
+            "dtype": "bf16x3 split products (hi.hi+hi.lo+lo.hi), f32 accumulate", "sweep_launch_ms": tl2 * 1e3,
+            "final_loss": lb,
+            "roofline": {"bound": "mfma", "kernel": "inbatch_bf16_sweep_kernel", "unit": "TFLOP/s",
+                         "achieved": 12.0 * bgd / tl2 / 1e12 if tl2 > 0 else 0.0, "peak": PEAK_BF16_MFMA_TFLOPS,
+                         "frac": 12.0 * bgd / tl2 / 1e12 / PEAK_BF16_MFMA_TFLOPS if tl2 > 0 else 0.0,
+                         "note": "executed bf16 MFMA FLOP per sweep launch (3 partial products x 4BGd)"},
+            "note": "optional precision mode of the dominant kernel; relative product error ~2^-16; same tests, "
+                    "looser tolerance (tests/test_gpu_towers.py::test_inbatch_bf16x3_precision_mode)"}
+        log(f"[bench] in-batch bf16x3: {G * K / dtb:,.0f} pairs/s, {dtb / K * 1e3:.2f} ms/step, sweep {tl2 * 1e3:.3f} ms/launch")
+    rows = cfg["item_shard"] == "rows" and world > 1
+    per_rank_gb = (cfg["users"] // world + (cfg["items"] // world if rows else cfg["items"])) * D * 4 * 3 / 1e9
+    config = {"workload": f"{cfg['name']}, d={D}, hidden={H}: Two-Tower BPR step, global batch {G} with global "
+                          f"in-batch negatives, row-sparse Adam, random-init MLPs, embedding rows U(-{INIT_HALF_WIDTH},"
+                          f"{INIT_HALF_WIDTH}); per-rank tables+moments {per_rank_gb:.1f} GB",
+              "config": cfg_name, "global_batch": G, "per_gpu_batch": B, "embed_dim": D, "loss_mode": "inbatch",
+              "parallelism": f"user rows sharded x{world}, item table "
+                             + (f"row-sharded x{world} (ids/rows/grads all-to-all)" if rows else
+                                ("replicated" if world > 1 else "on the one GPU"))}
+    res = dict(value=pairs_per_s, ms_per_step=dt / K * 1e3, loss=loss, roofline=roofline, config=config, modes=modes)
+    del tr, model, batches
+    torch.cuda.empty_cache()
+    return res
+
+
+def leg_sampled(cfg, args, world, rank, dev, cpu):
+    K, W = args.steps, args.warmup
+    Bs = 65536 // world
+    model, tr, n_users_local = build_trainer(cfg, world, rank, Bs, "sampled", seed=rank)
+    batches = make_batches(W + K, Bs, n_users_local, cfg["items"], dev, seed=9 + rank, sampled=True)
+    for i in range(W):
+        tr.step(*batches[i % len(batches)])
+    dts = timed(lambda i: tr.step(*batches[(W + i) % len(batches)]), K, world)
+    sp = Bs * world * K / dts
+    # SURVEY §8d per pair at d=128: 617 472 FLOP (fwd+bwd of three tower passes), 9 384 B of row traffic
+    f_mfma, f_hbm = sp * 617472 / (PEAK_F32_MFMA_TFLOPS * 1e12 * world), sp * 9384 / (PEAK_HBM_BYTES * world)
+    out = {"metric": "bpr_pairs_per_sec_sampled_negative", "value": sp, "unit": "pairs/s", "ms_per_step": dts / K * 1e3,
+           "global_batch": Bs * world, "final_loss": float(tr.loss.item()),
+           "roofline": {"bound": "mfma", "kernel": "tower_fwd2 / tower_bwd_data / tower_wgrad (exact f32)",
+                        "achieved": sp * 617472 / 1e12 / world, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": f_mfma, "frac_of_hbm_roofline": f_hbm,
+                        "note": "whole step (towers + loss + row-sparse optimiser) priced at the towers' algorithmic FLOP"}}
+    if cpu:
+        from oracle import torch_cpu_baseline as T
+        out["cpu_baseline"] = T.time_sampled_step(B=4096, n_users=65536, n_items=65536, d=D, hidden=H, budget_s=4.0)
+        out["cpu_baseline"]["note"] = ("dense Adam on 65 536-row tables stands in for the 10M-row ones (dense Adam over "
+                                       "10M rows would add 3 x 5 GB of traffic per step on the CPU)")
+    log(f"[bench] sampled: {sp:,.0f} pairs/s, {dts / K * 1e3:.2f} ms/step")
+    del tr, batches
+    return out, model
+
+
+def leg_ml1m(dev, cpu):
+    """BASELINE.json configs[0]/[1] shapes: 6041 x 64 + 3953 x 64 tables, dense Adam + L2 (the reference's optimiser)."""
+    from recommendit_amd.trainer import HipBPRTrainer
+    from recommendit_amd import TwoTowerModel
+    out = {}
+    for tag, (bb, mode) in {"cfg1_ml1m_d64_b256_sampled": (256, "sampled"),
+                            "cfg2_ml1m_d64_b8192_inbatch": (8192, "inbatch")}.items():
+        torch.manual_seed(5)
+        m2 = TwoTowerModel(6040, 3952, embed_dim=64, hidden_dim=128, dropout=0.1)
+        m2.train()
+        t2 = HipBPRTrainer(m2, bb, loss_mode=mode, table_opt="dense", seed=1)
+        b2 = make_batches(8, bb, 6040, 3952, dev, seed=11, sampled=(mode == "sampled"))
+        for i in range(5):
+            t2.step(*b2[i % 8])
+        n2 = 50
+        d2 = timed(lambda i: t2.step(*b2[i % 8]), n2, 1)
+        flop_pair = 322560.0 + (6.0 * bb * 64 if mode == "inbatch" else 0.0)   # SURVEY §8d, d=64
+        out[tag] = {"metric": "bpr_pairs_per_sec", "value": bb * n2 / d2, "unit": "pairs/s",
+                    "ms_per_step": d2 / n2 * 1e3, "batch": bb, "loss_mode": mode,
+                    "tables": "6041x64 + 3953x64 (MovieLens-1M shape), dense Adam+L2 (exact reference optimiser)",
+                    "roofline": {"bound": "mfma", "achieved": bb * n2 / d2 * flop_pair / 1e12,
+                                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": bb * n2 / d2 * flop_pair / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                 "note": "launch-bound regime: ~16 dependent kernel boundaries per step"}}
+        log(f"[bench] {tag}: {bb * n2 / d2:,.0f} pairs/s, {d2 / n2 * 1e3:.3f} ms/step")
+        del t2, m2, b2
+    if cpu:
+        from oracle import torch_cpu_baseline as T
+        c1 = T.time_sampled_step(B=256, budget_s=4.0)
+        smp = T.time_reference_sampler(budget_s=2.0)
+        c1["sampler_fed"] = {"value": min(c1["value"], 2 * smp["value"]), "unit": "pairs/s",
+                             "note": "reference DataLoader with 2 workers (train_embeddings.py:144-151): min(model-bound, "
+                                     "2 x per-worker sampler rate)", "sampler": smp}
+        out["cfg1_ml1m_d64_b256_sampled"]["cpu_baseline"] = c1
+        out["cfg2_ml1m_d64_b8192_inbatch"]["cpu_baseline"] = T.time_inbatch_block(G=8192, blk=8192, d=64, hidden=128,
+                                                                                   budget_s=3.0)
+    return out
+
+
+def leg_retrieval(model, cfg, n_users_local, args, world, rank, dev, cpu):
+    from recommendit_amd import FAISSIndex
+    K = args.steps
+    N = cfg["items"] if cfg["items"] <= 1_000_000 else 1_000_000     # BASELINE configs[2]: 1M-item corpus
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    X = torch.randn((N, D), device=dev, generator=g)
+    X = (X / X.norm(dim=1, keepdim=True)).contiguous()
+    idx = FAISSIndex(embed_dim=D, exact=True)
+    idx.build_from_device(X, np.arange(1, N + 1))
+    nq = 4096
+    g3 = torch.Generator(device=dev); g3.manual_seed(3 + rank)
+    qs = []
+    for i in range(2):   # pure-retrieval queries: L2-normalised N(0,1) (SURVEY.md §8d cfg3, seed 3)
+        qq = torch.randn((nq, D), device=dev, generator=g3)
+        qs.append((qq / qq.norm(dim=1, keepdim=True)).contiguous())
+    idx.batch_search_device(qs[0], k=K_TOP, normalized=True)
+    Kq = max(4, K)
+    dtq = timed(lambda i: idx.batch_search_device(qs[i % 2], k=K_TOP, normalized=True), Kq, world)
+    qps = nq * world * Kq / dtq
+    flop_q = 2.0 * N * D
+
+    def roof(q):
+        return {"bound": "mfma", "dtype": "bf16 filter pass", "kernel": "scan_bf16_kernel<128>",
+                "achieved": q * flop_q / 1e12 / world, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": q * flop_q / 1e12 / world / PEAK_BF16_MFMA_TFLOPS,
+                "vs_f32_mfma_peak": q * flop_q / 1e12 / world / PEAK_F32_MFMA_TFLOPS}
+
+    out = {"metric": "top500_ip_queries_per_sec", "value": qps, "unit": "queries/s", "ms_per_batch": dtq / Kq * 1e3,
+           "queries_per_batch": nq * world, "k": K_TOP, "queries": "L2-normalised N(0,1)",
+           "corpus": f"{N}x{D} f32 L2-normalised N(0,1), exact brute force (bf16-MFMA filter with proven completeness "
+                     f"+ exact f32 re-score; results identical to all-f32)", "roofline": roof(qps)}
+    log(f"[bench] retrieval: {qps:,.0f} q/s ({dtq / Kq * 1e3:.2f} ms per {nq} queries)")
+    # second distribution (SURVEY §8d cfg3): user-tower outputs against an item-tower-output corpus (clustered scores)
+    try:
+        model.eval()
+        with torch.no_grad():
+            ids = torch.arange(1, N + 1, device=dev)
+            gen = torch.Generator(device=dev); gen.manual_seed(17)
+            chunks = []
+            for s in range(0, N, 131072):
+                ii = ids[s:s + 131072]
+                gg = (torch.rand((ii.numel(), 18), device=dev, generator=gen) < 0.1).float()
+                chunks.append(model.item_tower(ii, gg))
+            Xt = torch.cat(chunks, 0).contiguous()
+            idx2 = FAISSIndex(embed_dim=D, exact=True)
+            idx2.build_from_device(Xt, np.arange(1, N + 1))
+            qt = [model.user_tower(torch.randint(1, n_users_local + 1, (nq,), device=dev, generator=g3)).contiguous()
+                  for _ in range(2)]
+        idx2.batch_search_device(qt[0], k=K_TOP, normalized=True)
+        dt2 = timed(lambda i: idx2.batch_search_device(qt[i % 2], k=K_TOP, normalized=True), Kq, world)
+        q2 = nq * world * Kq / dt2
+        out["tower_outputs"] = {"value": q2, "unit": "queries/s", "ms_per_batch": dt2 / Kq * 1e3,
+                                "queries": "user-tower outputs", "corpus": f"item-tower outputs of {N} items",
+                                "roofline": roof(q2)}
+        # PCIe-inclusive: the reference API hands over / returns host NumPy arrays (faiss_index.py:126-153)
+        qh = qt[0].cpu().numpy()
+        idx2.batch_search(qh, k=K_TOP)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(3):
+            idx2.batch_search(qh, k=K_TOP)
+        out["tower_outputs"]["pcie_inclusive_qps"] = 3 * nq / (time.perf_counter() - t0)
+        log(f"[bench] retrieval (tower outputs): {q2:,.0f} q/s, host-array API {out['tower_outputs']['pcie_inclusive_qps']:,.0f} q/s")
+        del idx2, Xt, qt
+    except Exception as e:  # never take the headline down
+        out["tower_outputs"] = {"error": repr(e)}
+        log(f"[bench] retrieval tower-output leg failed: {e!r}")
+    if cpu:
+        from oracle import torch_cpu_baseline as T
+        out["cpu_baseline"] = T.time_retrieval(N=N, d=D, k=K_TOP, budget_s=6.0)
+    return out, idx, X
+
+
+def leg_serve(model, X, n_users_local, dev, cpu):
+    """cfg5: user tower -> IVF-IP (100 lists, nprobe 10, 500 candidates) -> feature assembly -> LambdaMART -> top-20"""
+    import tempfile
+    from recommendit_amd import synthetic as GB
+    from recommendit_amd import FAISSIndex, LightGBMRanker
+    from recommendit_amd.recommender import GpuFeatureStore, GpuRecommendationPipeline, feature_columns
+    N = X.shape[0]
+    ivf = FAISSIndex(embed_dim=D, n_lists=100, n_probe=10)
+    t0 = time.perf_counter()
+    ivf.build_from_device(X, np.arange(1, N + 1))
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    forest = GB.random_forest_model(500, 63, 50, seed=4, names=feature_columns())
+    text = GB.write_text_model(forest)
+    with tempfile.TemporaryDirectory() as td:
+        pth = os.path.join(td, "f.lgbm")
+        open(pth, "w").write(text)
+        ranker = LightGBMRanker.load(pth)
+    store = GpuFeatureStore(8, 8)          # tiny host tables; device tables built directly below
+    gg = torch.Generator(device=dev); gg.manual_seed(5)
+    store._dev = (torch.rand((n_users_local + 1, 24), device=dev, generator=gg, dtype=torch.float64),
+                  torch.rand((N + 1, 23), device=dev, generator=gg, dtype=torch.float64))
+    pipe = GpuRecommendationPipeline(model, ivf, ranker, store, top_k_candidates=K_TOP, top_k_results=20)
+    nqs = 256
+    uids = [torch.randint(1, n_users_local + 1, (nqs,), device=dev, generator=gg) for _ in range(3)]
+    pipe.recommend_batch(uids[0])
+    dts = timed(lambda i: pipe.recommend_batch(uids[i % 3]), 6, 1)
+    one = uids[0][:1]
+    pipe.recommend_batch(one)
+    lat = []
+    for _ in range(20):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        pipe.recommend_batch(one)
+        torch.cuda.synchronize(); lat.append((time.perf_counter() - t0) * 1e3)
+    lat.sort()
+    rps = nqs * 6 / dts
+    # ranker alone on the candidates of one batch: node visits / s (neither HBM nor MFMA bound: dependent LDS reads)
+    Xf = torch.rand((nqs * K_TOP, 50), device=dev, generator=gg)
+    ranker.predict_device(Xf)
+    dtr = timed(lambda i: ranker.predict_device(Xf), 5, 1)
+    out = {"metric": "end_to_end_recommendations_per_sec", "value": rps, "unit": "requests/s", "batch": nqs,
+           "single_request_ms_p50": lat[len(lat) // 2], "single_request_ms_max": lat[-1], "ivf_build_s": build_s,
+           "pipeline": "user tower -> IVF-IP(100 lists, nprobe 10, 500 cands) -> feature assembly -> LambdaMART 500 "
+                       "trees x 63 leaves x 50 features -> top-20",
+           "ranker": {"candidates_per_s": nqs * K_TOP * 5 / dtr, "tree_walks_per_s": nqs * K_TOP * 5 / dtr * 500,
+                      "ms_per_128k_candidates": dtr / 5 * 1e3,
+                      "roofline": {"bound": "neither", "note": "forest (1 MB) is LDS-resident; chains of dependent LDS "
+                                   "reads bound the walk (SURVEY §8d): HBM/MFMA fractions are not meaningful",
+                                   "hbm_frac": nqs * K_TOP * 5 / dtr * 208 / PEAK_HBM_BYTES}}}
+    log(f"[bench] serve: {rps:,.0f} req/s batched, {lat[len(lat) // 2]:.2f} ms p50 single; ranker "
+        f"{nqs * K_TOP * 5 / dtr / 1e6:.1f} M candidates/s")
+    if cpu:
+        from oracle import gbdt_np as G
+        from oracle import torch_cpu_baseline as T
+        out["ranker"]["cpu_baseline"] = T.time_tree_walk(G.parse_text_model(text), 50, n=8192, budget_s=4.0)
+    return out
 
 
 def main():
@@ -132,10 +466,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--global-batch", type=int, default=GLOBAL_BATCH)
+    ap.add_argument("--config", choices=["auto", "cfg3", "cfg4"], default="auto")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--users", type=int, default=N_USERS)
-    ap.add_argument("--items", type=int, default=N_ITEMS)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -148,256 +481,54 @@ def main():
     dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("RIHIP_DIST_BACKEND", "nccl")   # "gloo": CPU-staged rehearsal of the N>1 path
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    assert args.global_batch % world == 0
+    cfg_name = args.config if args.config != "auto" else ("cfg4" if world == 8 else "cfg3")
+    cpu_ok = rank == 0 and world == 1 and not args.no_cpu_baseline
+    log(f"[bench] host threads: torch.get_num_threads()={torch.get_num_threads()}, os.cpu_count()={os.cpu_count()}")
 
-    from recommendit_amd.trainer import HipBPRTrainer
-    G = args.global_batch
-    assert G % world == 0
-    B = G // world
-    n_users_local = args.users // world
-    K, W = args.steps, args.warmup
-
-    # ------------------------------------------------------------------ headline: in-batch BPR
-    model = make_model(n_users_local, args.items, D, H, seed=1234)  # same seed: replicated item table + MLPs
-    if world > 1:  # user shards differ per rank
-        g = torch.Generator(device=dev); g.manual_seed(100 + rank)
-        model.user_tower.embedding.weight.data.uniform_(-0.0007, 0.0007, generator=g)
-    tr = HipBPRTrainer(model, B, lr=1e-3, weight_decay=1e-5, loss_mode="inbatch", table_opt="sparse", seed=rank,
-                       process_group=None)
-    batches = make_batches(W + K, B, n_users_local, args.items, dev, seed=7 + rank, sampled=False)
-    ev = []
-
-    def step(i):
-        u, it, g = batches[i % len(batches)]
-        tr.step(u, it, g)
-
-    for i in range(W):
-        step(i)
-    # per-launch duration of the dominant kernel, measured on the launch stream inside the timed region
-    tr.sweep_events = ev
-    dt = timed(lambda i: step(W + i), K, world)
-    tr.sweep_events = None
-    loss = float(tr.loss.item())
-    pairs_per_s = G * K / dt
-    by = {}
-    for what, e0, e1 in ev:                            # one bracket per launch, keyed by the C-ABI call
-        by.setdefault(what, []).append(e0.elapsed_time(e1))
-    mean_ms = {k: sum(v) / len(v) for k, v in by.items()}
-    traffic_tab = {}
-    tf = ROOT / "profiles" / "traffic.json"
-    if tf.exists():
-        try:
-            traffic_tab = json.loads(tf.read_text())
-        except Exception:
-            traffic_tab = {}
-    bgd = float(B) * G * D
-    if "inbatch_user_pass" in mean_ms:
-        # stored-G form: the user pass computes the scores once (2BGd) and dU (2BGd) and writes G; the item pass is
-        # dI = G^T.U (2BGd).  Executed = algorithmic = 6*B_neg*d per pair.
-        t_launch = mean_ms["inbatch_user_pass"] / 1e3
-        flop_launch = 4.0 * bgd
-        achieved = flop_launch / t_launch / 1e12
-        t_item = mean_ms["inbatch_item_pass"] / 1e3
-        roofline = {"bound": "mfma", "kernel": "inbatch_sweep_kernel<128,user,store-G>", "achieved": achieved,
-                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                    "traffic": traffic_tab.get(f"inbatch_user_pass_n{world}"), "launch_ms": t_launch * 1e3,
-                    "algorithmic_flop_per_launch": flop_launch, "executed_flop_per_launch": flop_launch,
-                    "second_kernel": {"kernel": "inbatch_gt_kernel<128>", "launch_ms": t_item * 1e3,
-                                      "algorithmic_flop_per_launch": 2.0 * bgd,
-                                      "achieved": 2.0 * bgd / t_item / 1e12,
-                                      "frac": 2.0 * bgd / t_item / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                      "traffic": traffic_tab.get(f"inbatch_item_pass_n{world}")},
-                    "loss_stage_algorithmic_tflops": 6.0 * bgd / (t_launch + t_item) / 1e12}
-        log(f"[bench] in-batch: {pairs_per_s:,.0f} pairs/s, {dt / K * 1e3:.2f} ms/step, loss {loss:.4f}, user pass "
-            f"{t_launch * 1e3:.3f} ms = {achieved:.1f} TFLOP/s, item pass {t_item * 1e3:.3f} ms = "
-            f"{2.0 * bgd / t_item / 1e12:.1f} TFLOP/s")
-    else:
-        t_launch = mean_ms.get("inbatch_sweep", 0.0) / 1e3
-        flop_launch = 3.0 * bgd                       # algorithmic: 6*B_neg*d per pair / 2 launches
-        achieved = flop_launch / t_launch / 1e12 if t_launch > 0 else 0.0
-        roofline = {"bound": "mfma", "kernel": "inbatch_sweep_kernel<128>", "achieved": achieved,
-                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                    "traffic": traffic_tab.get(f"inbatch_sweep_n{world}"), "launch_ms": t_launch * 1e3,
-                    "algorithmic_flop_per_launch": flop_launch, "executed_flop_per_launch": 4.0 * bgd}
-        log(f"[bench] in-batch: {pairs_per_s:,.0f} pairs/s, {dt / K * 1e3:.2f} ms/step, loss {loss:.4f}, "
-            f"sweep {t_launch * 1e3:.3f} ms/launch = {achieved:.1f} TFLOP/s algorithmic")
-    flop_launch_rc = 3.0 * bgd
-    secondary = {}
+    head = headline(cfg_name, args, world, rank, dev, want_modes=not args.no_secondary)
+    secondary = dict(head.pop("modes"))
     if not args.no_secondary:
-        # ---------------------------------------------------------- same step, stored-G passes on split-bf16 MFMA
-        # with fp32-level accuracy ("bf16x6": exact 3-way operand split, 6 partial products; same test tolerances)
-        tr.inbatch_precision = 2
-        for i in range(W):
-            step(i)
-        ev6 = []
-        tr.sweep_events = ev6
-        dt6 = timed(lambda i: step(W + i), K, world)
-        tr.sweep_events = None
-        by6 = {}
-        for what, e0, e1 in ev6:
-            by6.setdefault(what, []).append(e0.elapsed_time(e1))
-        m6 = {k: sum(v) / len(v) for k, v in by6.items()}
-        tu6, ti6 = m6.get("inbatch_user_pass", 0.0) / 1e3, m6.get("inbatch_item_pass", 0.0) / 1e3
-        secondary["inbatch_bf16x6"] = {
-            "metric": "bpr_pairs_per_sec", "value": G * K / dt6, "unit": "pairs/s", "ms_per_step": dt6 / K * 1e3,
-            "dtype": "bf16x6: fp32 operands split exactly into 3 bf16 pieces, 6 of 9 partial products on bf16 MFMA, "
-                     "f32 accumulate (dropped terms <= 2^-23 |a||b|)",
-            "user_pass_ms": tu6 * 1e3, "item_pass_ms": ti6 * 1e3,
-            "algorithmic_tflops_user_pass": 4.0 * bgd / tu6 / 1e12 if tu6 > 0 else 0.0,
-            "executed_bf16_tflops_user_pass": 24.0 * bgd / tu6 / 1e12 if tu6 > 0 else 0.0,
-            "frac_of_bf16_dense_peak_executed": 24.0 * bgd / tu6 / 1e12 / 2500.0 if tu6 > 0 else 0.0,
-            "final_loss": float(tr.loss.item()),
-            "note": "optional precision mode (HipBPRTrainer(inbatch_precision=2)); held to the SAME tolerances as the "
-                    "f32-MFMA path in tests/test_gpu_towers.py; the chip runs it power-limited at ~1.8 GHz"}
-        log(f"[bench] in-batch bf16x6: {G * K / dt6:,.0f} pairs/s, {dt6 / K * 1e3:.2f} ms/step, user pass "
-            f"{tu6 * 1e3:.3f} ms, item pass {ti6 * 1e3:.3f} ms")
-        # ---------------------------------------------------------- same step with the split-bf16 ("bf16x3") sweep
-        tr.inbatch_precision = 1
-        for i in range(W):
-            step(i)
-        ev2 = []
-        tr.sweep_events = ev2
-        dtb = timed(lambda i: step(W + i), K, world)
-        tr.sweep_events = None
-        ms2 = [a_.elapsed_time(b_) for _, a_, b_ in ev2]
-        tl2 = sum(ms2) / 1e3 / max(len(ms2), 1)
-        secondary["inbatch_bf16x3"] = {
-            "metric": "bpr_pairs_per_sec", "value": G * K / dtb, "unit": "pairs/s", "ms_per_step": dtb / K * 1e3,
-            "dtype": "bf16x3 split products (hi.hi+hi.lo+lo.hi), f32 accumulate", "sweep_launch_ms": tl2 * 1e3,
-            "algorithmic_tflops": flop_launch_rc / tl2 / 1e12 if tl2 > 0 else 0.0, "final_loss": float(tr.loss.item()),
-            "note": "optional precision mode of the dominant kernel; relative product error ~2^-16; same tests, "
-                    "looser tolerance (tests/test_gpu_towers.py::test_inbatch_bf16x3_precision_mode)"}
-        log(f"[bench] in-batch bf16x3: {G * K / dtb:,.0f} pairs/s, {dtb / K * 1e3:.2f} ms/step, sweep {tl2 * 1e3:.3f} ms/launch")
-    del tr, model, batches
-    torch.cuda.empty_cache()
-
-    if not args.no_secondary:
-        # -------------------------------------------------------------- sampled-negative BPR (reference's mode)
-        Bs = 65536 // world
-        model = make_model(n_users_local, args.items, D, H, seed=1234)
-        tr = HipBPRTrainer(model, Bs, loss_mode="sampled", table_opt="sparse", seed=rank)
-        batches = make_batches(W + K, Bs, n_users_local, args.items, dev, seed=9 + rank, sampled=True)
-        for i in range(W):
-            tr.step(*batches[i % len(batches)])
-        dts = timed(lambda i: tr.step(*batches[(W + i) % len(batches)]), K, world)
-        sp = Bs * world * K / dts
-        # HBM roofline of the sparse formulation: 9 384 B/pair at d=128; MFMA: 617 472 FLOP/pair
-        secondary["sampled_bpr"] = {"metric": "bpr_pairs_per_sec_sampled_negative", "value": sp, "unit": "pairs/s",
-                                    "ms_per_step": dts / K * 1e3, "global_batch": Bs * world,
-                                    "frac_of_f32_mfma_roofline": sp * 617472 / (PEAK_F32_MFMA_TFLOPS * 1e12 * world),
-                                    "frac_of_hbm_roofline": sp * 9384 / (8.0e12 * world)}
-        log(f"[bench] sampled: {sp:,.0f} pairs/s, {dts / K * 1e3:.2f} ms/step")
-        # -------------------------------------------------------------- BASELINE.json configs[0]/[1] shapes (1 GPU only)
+        if world == 8 and cfg_name != "cfg3":
+            # the strong-scaling curve's own point: the N<8 runs use the cfg3 tables
+            alt = headline("cfg3", args, world, rank, dev, want_modes=False)
+            secondary["inbatch_cfg3_tables"] = {"metric": "bpr_pairs_per_sec", "value": alt["value"], "unit": "pairs/s",
+                                                "ms_per_step": alt["ms_per_step"], "roofline": alt["roofline"],
+                                                "config": alt["config"]}
+        cfg = CONFIGS["cfg3"]        # secondary legs run on the cfg3 tables
+        sampled, model = leg_sampled(cfg, args, world, rank, dev, cpu_ok)
+        secondary["sampled_bpr"] = sampled
+        n_users_local = cfg["users"] // world
         if world == 1:
-            for tag, (bb, mode) in {"cfg1_ml1m_d64_b256_sampled": (256, "sampled"),
-                                    "cfg2_ml1m_d64_b8192_inbatch": (8192, "inbatch")}.items():
-                m2 = make_model(6040, 3952, 64, 128, seed=5)
-                # dense Adam + L2 on every row = the reference's exact optimiser semantics (tables are 2.5 MB)
-                t2 = HipBPRTrainer(m2, bb, loss_mode=mode, table_opt="dense", seed=1)
-                b2 = make_batches(8, bb, 6040, 3952, dev, seed=11, sampled=(mode == "sampled"))
-                for i in range(5):
-                    t2.step(*b2[i % 8])
-                n2 = 50
-                d2 = timed(lambda i: t2.step(*b2[i % 8]), n2, 1)
-                secondary[tag] = {"metric": "bpr_pairs_per_sec", "value": bb * n2 / d2, "unit": "pairs/s",
-                                  "ms_per_step": d2 / n2 * 1e3, "batch": bb, "loss_mode": mode,
-                                  "tables": "6041x64 + 3953x64 (MovieLens-1M shape), dense Adam+L2 (exact reference optimiser)"}
-                log(f"[bench] {tag}: {bb * n2 / d2:,.0f} pairs/s, {d2 / n2 * 1e3:.3f} ms/step")
-                del t2, m2, b2
-        # -------------------------------------------------------------- top-500 brute-force IP retrieval
-        from recommendit_amd import FAISSIndex
-        g = torch.Generator(device=dev); g.manual_seed(1)
-        X = torch.randn((args.items, D), device=dev, generator=g)
-        X = (X / X.norm(dim=1, keepdim=True)).contiguous()
-        idx = FAISSIndex(embed_dim=D, exact=True)
-        idx.build_from_device(X, np.arange(1, args.items + 1))
-        nq = 4096
-        model.eval()
-        qs = []
-        g3 = torch.Generator(device=dev); g3.manual_seed(3 + rank)
-        for i in range(2):   # pure-retrieval queries: L2-normalised N(0,1) (seed 3)
-            qq = torch.randn((nq, D), device=dev, generator=g3)
-            qs.append((qq / qq.norm(dim=1, keepdim=True)).contiguous())
-        for i in range(1):
-            idx.batch_search_device(qs[0], k=K_TOP, normalized=True)
-        Kq = max(4, K)
-        dtq = timed(lambda i: idx.batch_search_device(qs[i % 2], k=K_TOP, normalized=True), Kq, world)
-        qps = nq * world * Kq / dtq
-        flop_q = 2.0 * args.items * D
-        secondary["retrieval"] = {"metric": "top500_ip_queries_per_sec", "value": qps, "unit": "queries/s",
-                                  "ms_per_batch": dtq / Kq * 1e3, "queries_per_batch": nq * world, "k": K_TOP,
-                                  "corpus": f"{args.items}x{D} f32, exact brute force (bf16-MFMA filter with proven "
-                                            f"completeness + exact f32 re-score; results identical to all-f32)",
-                                  "roofline": {"bound": "mfma", "dtype": "bf16 filter pass",
-                                               "achieved": qps * flop_q / 1e12 / world, "peak": 2500.0,
-                                               "unit": "TFLOP/s", "frac": qps * flop_q / 1e12 / world / 2500.0,
-                                               "vs_f32_mfma_peak": qps * flop_q / 1e12 / world / PEAK_F32_MFMA_TFLOPS}}
-        log(f"[bench] retrieval: {qps:,.0f} q/s ({dtq / Kq * 1e3:.2f} ms per {nq} queries)")
-        # -------------------------------------------------------------- cfg5: end-to-end serve (1 GPU only)
+            secondary.update(leg_ml1m(dev, cpu_ok))
+        retr, idx, X = leg_retrieval(model, cfg, n_users_local, args, world, rank, dev, cpu_ok)
+        secondary["retrieval"] = retr
         if world == 1:
             try:
-                from recommendit_amd import synthetic as GB
-                from recommendit_amd import LightGBMRanker
-                from recommendit_amd.recommender import GpuFeatureStore, GpuRecommendationPipeline, feature_columns
-                import tempfile
-                ivf = FAISSIndex(embed_dim=D, n_lists=100, n_probe=10)
-                t0 = time.perf_counter()
-                ivf.build_from_device(X, np.arange(1, args.items + 1))
-                torch.cuda.synchronize()
-                build_s = time.perf_counter() - t0
-                forest = GB.random_forest_model(500, 63, 50, seed=4, names=feature_columns())
-                with tempfile.TemporaryDirectory() as td:
-                    pth = os.path.join(td, "f.lgbm")
-                    open(pth, "w").write(GB.write_text_model(forest))
-                    ranker = LightGBMRanker.load(pth)
-                store = GpuFeatureStore(8, 8)          # tiny host tables; device tables built directly below
-                gg = torch.Generator(device=dev); gg.manual_seed(5)
-                store._dev = (torch.rand((n_users_local + 1, 24), device=dev, generator=gg, dtype=torch.float64),
-                              torch.rand((args.items + 1, 23), device=dev, generator=gg, dtype=torch.float64))
-                pipe = GpuRecommendationPipeline(model, ivf, ranker, store, top_k_candidates=K_TOP, top_k_results=20)
-                nqs = 256
-                uids = [torch.randint(1, n_users_local + 1, (nqs,), device=dev, generator=g) for _ in range(3)]
-                pipe.recommend_batch(uids[0])
-                dts = timed(lambda i: pipe.recommend_batch(uids[i % 3]), 3, 1)
-                one = uids[0][:1]
-                pipe.recommend_batch(one)
-                lat = []
-                for _ in range(20):
-                    torch.cuda.synchronize(); t0 = time.perf_counter()
-                    pipe.recommend_batch(one)
-                    torch.cuda.synchronize(); lat.append((time.perf_counter() - t0) * 1e3)
-                lat.sort()
-                secondary["serve"] = {"metric": "end_to_end_recommendations_per_sec", "value": nqs * 3 / dts,
-                                      "unit": "requests/s", "batch": nqs, "single_request_ms_p50": lat[len(lat) // 2],
-                                      "single_request_ms_max": lat[-1], "ivf_build_s": build_s,
-                                      "pipeline": "user tower -> IVF-IP(100 lists, nprobe 10, 500 cands) -> feature "
-                                                  "assembly -> LambdaMART 500 trees x 63 leaves x 50 features -> top-20"}
-                log(f"[bench] serve: {nqs * 3 / dts:,.0f} req/s batched, {lat[len(lat) // 2]:.2f} ms p50 single")
-                del pipe, ivf, ranker, store
+                secondary["serve"] = leg_serve(model, X, n_users_local, dev, cpu_ok)
             except Exception as e:  # the serve leg must never take the headline down
                 secondary["serve"] = {"error": repr(e)}
                 log(f"[bench] serve leg failed: {e!r}")
-        del tr, model, idx, X
+        del model, idx, X
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline_inbatch()
-        log(f"[bench] cpu oracle: {cpu['value']:.1f} pairs/s on {cpu['cores']} threads")
+    if cpu_ok:
+        from oracle import torch_cpu_baseline as T
+        cpu = T.time_inbatch_block(G=args.global_batch, blk=2048, d=D, hidden=H, budget_s=8.0)
+        log(f"[bench] cpu (torch f32, {cpu['cores']} threads): {cpu['value']:.1f} pairs/s")
 
     if rank == 0:
         line = {
-            "metric": "bpr_pairs_per_sec", "value": pairs_per_s, "unit": "pairs/s", "n_gpus": world, "steps": K,
-            "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"synthetic {args.users // 1_000_000}M users x {args.items // 1_000_000}M items, "
-                                   f"d={D}, hidden={H}: Two-Tower BPR step, global batch {G} with global in-batch "
-                                   f"negatives, row-sparse Adam, random-init weights",
-                       "global_batch": G, "per_gpu_batch": B, "embed_dim": D, "loss_mode": "inbatch",
-                       "parallelism": f"user-row-shard x{world}, item table replicated"},
-            "final_loss": loss, "roofline": roofline, "cpu_baseline": cpu, "secondary": secondary,
+            "metric": "bpr_pairs_per_sec", "value": head["value"], "unit": "pairs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": head["config"],
+            "final_loss": head["loss"], "git_head": git_head(), "roofline": head["roofline"], "cpu_baseline": cpu,
+            "secondary": secondary,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

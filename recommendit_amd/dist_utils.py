@@ -53,6 +53,15 @@ def all_reduce_sum_(t: torch.Tensor, group=None) -> None:
         dist.all_reduce(t, group=group)
 
 
+def broadcast_(t: torch.Tensor, src: int = 0, group=None) -> None:
+    if _staged(t, group):
+        c = t.detach().cpu()
+        dist.broadcast(c, src, group=group)
+        t.copy_(c.to(t.device))
+    else:
+        dist.broadcast(t, src, group=group)
+
+
 def reduce_scatter_sum(out: torch.Tensor, inp: torch.Tensor, group=None, async_op: bool = False):
     """out = (sum over ranks of inp)[rank*n:(rank+1)*n], n = out.shape[0] (rows).  Same async contract as
     all_gather_into."""
