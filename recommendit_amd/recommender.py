@@ -74,6 +74,63 @@ class GpuFeatureStore:
             self.item[: len(item_tab)] = item_tab
         self._dev = None
 
+    def load_all_features(self, user_features_df, item_features_df, batch_size: int = 500) -> None:
+        """Bulk load from the DataFrames the reference's FeatureEngineer produces / saves (same entry point and column
+        conventions as RedisFeatureStore.load_all_features, src/features/feature_store.py:156-228): scalar columns by
+        name, `genre_pref_<i>` / `genre_vec_<i>` expanded columns (feature_engineering.py:382-404) or the un-expanded
+        `genre_pref` / `genre_vector` array columns; columns that are absent keep the defaults of
+        _build_ranking_features (recommender.py:227-238); ids beyond the table size grow it.  Vectorised: no per-row
+        Python loop (the reference iterates rows and msgpack-serialises each one)."""
+        def fill(tab, df, id_col, scalars, vec_prefix, vec_col, off):
+            if df is None or len(df) == 0:
+                return tab
+            ids = df[id_col].to_numpy().astype(np.int64)
+            if ids.min() < 0:
+                raise ValueError(f"negative {id_col}")
+            if ids.max() >= tab.shape[0]:          # grow, new rows at their defaults
+                grown = np.repeat(tab[:1].copy(), int(ids.max()) + 1, axis=0)
+                grown[:, :] = self._default_row(tab.shape[1], scalars)
+                grown[: tab.shape[0]] = tab
+                tab = grown
+            for j, (name, _) in enumerate(scalars):
+                if name in df.columns:
+                    tab[ids, j] = df[name].to_numpy().astype(np.float64)
+            vec_cols = [f"{vec_prefix}{i}" for i in range(N_GENRES)]
+            if all(c in df.columns for c in vec_cols):
+                tab[ids, off:off + N_GENRES] = df[vec_cols].to_numpy().astype(np.float64)
+            elif vec_col in df.columns:
+                tab[ids, off:off + N_GENRES] = np.stack([np.asarray(v, dtype=np.float64)[:N_GENRES]
+                                                         for v in df[vec_col].to_numpy()])
+            return tab
+
+        self.user = fill(self.user, user_features_df, "user_id", USER_SCALARS, "genre_pref_", "genre_pref", 6)
+        self.item = fill(self.item, item_features_df, "item_id", ITEM_SCALARS, "genre_vec_", "genre_vector", 5)
+        self._dev = None
+
+    @staticmethod
+    def _default_row(width: int, scalars) -> np.ndarray:
+        row = np.zeros((width,), dtype=np.float64)
+        row[: len(scalars)] = [d for _, d in scalars]
+        return row
+
+    @classmethod
+    def from_parquet(cls, features_dir: str, n_users: int = 0, n_items: int = 0) -> "GpuFeatureStore":
+        """Device feature tables straight from `user_features.parquet` / `item_features.parquet` as written by
+        FeatureEngineer.save_features (src/features/feature_engineering.py:376-406) -- the parquet -> device-table
+        loader SURVEY.md §8f-1 names.  A missing file leaves that table at its defaults (the reference's
+        load_features skips missing files too, :415, :425)."""
+        import pandas as pd
+        from pathlib import Path
+        d = Path(features_dir)
+        up, ip = d / "user_features.parquet", d / "item_features.parquet"
+        udf = pd.read_parquet(up) if up.exists() else None
+        idf = pd.read_parquet(ip) if ip.exists() else None
+        nu = max(n_users, int(udf["user_id"].max()) if udf is not None and len(udf) else 0)
+        ni = max(n_items, int(idf["item_id"].max()) if idf is not None and len(idf) else 0)
+        st = cls(nu, ni)
+        st.load_all_features(udf, idf)
+        return st
+
     def device_tables(self) -> Tuple[torch.Tensor, torch.Tensor]:
         if self._dev is None:
             dev = L.device()

@@ -177,6 +177,18 @@ def test_g3_inbatch_golden(golden_dir, B):
     np.testing.assert_allclose(I.grad.cpu().numpy(), g[f"B{B}_dI"], atol=3e-8, rtol=3e-4)
 
 
+@pytest.mark.parametrize("store_g", [True, False])
+@pytest.mark.parametrize("B", [2, 16, 256, 96])
+def test_g3_inbatch_golden_bf16x6(golden_dir, B, store_g):
+    """the reference's own in_batch_bpr_loss outputs (G3) against the split-bf16 mode (precision=2), SAME tolerances"""
+    from recommendit_amd.two_tower import inbatch_loss_and_grads
+    g = np.load(golden_dir / "g3_inbatch.npz")
+    loss, dU, dI = inbatch_loss_and_grads(t(g[f"B{B}_U"]), t(g[f"B{B}_I"]), precision=2, store_g=store_g)
+    assert abs(loss.item() - float(g[f"B{B}_loss"])) < 3e-6
+    np.testing.assert_allclose(dU.cpu().numpy(), g[f"B{B}_dU"], atol=3e-8, rtol=3e-4)
+    np.testing.assert_allclose(dI.cpu().numpy(), g[f"B{B}_dI"], atol=3e-8, rtol=3e-4)
+
+
 @pytest.mark.parametrize("prec", [0, 2])   # 2 = bf16x6: fp32-level accuracy, held to the SAME tolerances as f32 MFMA
 @pytest.mark.parametrize("B,d", [(33, 32), (130, 64), (500, 128), (1024, 64)])
 def test_inbatch_vs_oracle_ragged_and_reproducible(B, d, prec):

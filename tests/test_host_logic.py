@@ -105,3 +105,44 @@ def test_error_conventions_without_backend_calls(tmp_path):
         LightGBMRanker.load(str(tmp_path / "none.lgbm"))
     assert LightGBMRanker().model_info() == {"status": "not trained"}
     assert LightGBMRanker().best_iteration == 0 and LightGBMRanker().n_features == 0
+
+
+def test_feature_store_parquet_loader_matches_row_by_row_path(tmp_path):
+    """GpuFeatureStore.from_parquet / load_all_features (vectorised) against the per-row dict route that restates the
+    reference's RedisFeatureStore.load_all_features (src/features/feature_store.py:156-228), on files laid out as
+    FeatureEngineer.save_features writes them (feature_engineering.py:376-406): scalars + genre_pref_<i> / genre_vec_<i>."""
+    import pandas as pd
+    from recommendit_amd.recommender import GpuFeatureStore, ITEM_SCALARS, USER_SCALARS
+    rng = np.random.RandomState(0)
+    nu, ni = 40, 55
+    uids = rng.permutation(np.arange(1, nu + 1))[:33]                       # some users have no features
+    iids = rng.permutation(np.arange(1, ni + 1))[:50]
+    udf = pd.DataFrame({"user_id": uids, **{n: rng.rand(len(uids)) * 5 for n, _ in USER_SCALARS if n != "recency_score"},
+                        **{f"genre_pref_{i}": rng.rand(len(uids)).astype(np.float32) for i in range(18)},
+                        "rating_count": rng.randint(1, 99, len(uids))})    # extra column the ranker never reads
+    idf = pd.DataFrame({"item_id": iids, "title": [f"Movie {i}" for i in iids],
+                        **{n: rng.rand(len(iids)) * 3 for n, _ in ITEM_SCALARS},
+                        **{f"genre_vec_{i}": (rng.rand(len(iids)) < 0.2).astype(np.float32) for i in range(18)}})
+    udf.to_parquet(tmp_path / "user_features.parquet", index=False)
+    idf.to_parquet(tmp_path / "item_features.parquet", index=False)
+    st = GpuFeatureStore.from_parquet(str(tmp_path), n_users=nu, n_items=ni)
+    ref = GpuFeatureStore(nu, ni)
+    gp = [f"genre_pref_{i}" for i in range(18)]
+    gv = [f"genre_vec_{i}" for i in range(18)]
+    for _, row in pd.read_parquet(tmp_path / "user_features.parquet").iterrows():     # feature_store.py:183-191
+        feat = {c: row[c] for c in udf.columns if c != "user_id" and c not in gp}
+        feat["genre_pref"] = [float(row[c]) for c in gp]
+        ref.set_user_features(int(row["user_id"]), feat)
+    for _, row in pd.read_parquet(tmp_path / "item_features.parquet").iterrows():     # feature_store.py:211-221
+        feat = {c: row[c] for c in idf.columns if c not in ("item_id", "title") and c not in gv}
+        feat["genre_vector"] = [float(row[c]) for c in gv]
+        ref.set_item_features(int(row["item_id"]), feat)
+    np.testing.assert_array_equal(st.user, ref.user)
+    np.testing.assert_array_equal(st.item, ref.item)
+    assert (st.user[:, 2] == 0.5).all()                                       # absent column keeps its default
+    missing = sorted(set(range(1, nu + 1)) - set(uids.tolist()))
+    assert (st.user[missing, :6] == [d for _, d in USER_SCALARS]).all()
+    # ids beyond the declared size grow the table; un-expanded array columns are accepted too
+    st2 = GpuFeatureStore(3, 3)
+    st2.load_all_features(pd.DataFrame({"user_id": [9], "avg_rating": [4.5], "genre_pref": [list(range(18))]}), None)
+    assert st2.user.shape[0] == 10 and st2.user[9, 0] == 4.5 and st2.user[9, 6 + 17] == 17.0 and st2.user[5, 0] == 3.5
