@@ -5,9 +5,12 @@ search, batch_search, save/load (+ ``<stem>.meta.pkl`` sidecar with the same key
 set_n_probe, and the ``index`` attribute (``index.ntotal``, writable ``index.nprobe``) that
 tests/test_models.py:170-171,:223 read.  Error types/messages follow the reference.
 
-The index file itself is the library's own "RIHIPIDX" format (faiss.write_index files cannot be
-read without faiss).  The k-means trainer is the library's own, so IVF list
-membership differs from faiss's: parity is property-level.
+Index files: ``save(path)`` writes the library's own "RIHIPIDX" format by default and a FAISS ``IndexIVFFlat`` /
+``IndexFlatIP`` file with ``format="faiss"``; ``load(path)`` sniffs the magic and reads either (faiss_io.py; the FAISS
+layout is restated from faiss 1.7.x and unverifiable offline: parity unpinned).  The k-means trainer is
+the library's own, so the IVF list membership of an index TRAINED here differs from one trained by faiss; an index
+LOADED from a faiss file keeps faiss's centroids and lists.  Limits the reference (faiss) does not have: embed_dim in
+{32, 64, 128}, n_lists <= 2048, k <= 16384 (INTEGRATION.md).
 """
 from __future__ import annotations
 
@@ -209,10 +212,21 @@ class FAISSIndex:
         return scores, rows
 
     # -- persistence (faiss_index.py:159-205) -------------------------------------------------
-    def save(self, path: str) -> None:
+    def save(self, path: str, format: str = "rihip") -> None:
+        """format="faiss": a file faiss.read_index can open (IndexIVFFlat, or IndexFlatIP for exact=True)."""
         save_path = Path(path)
         save_path.parent.mkdir(parents=True, exist_ok=True)
-        L.check(L.lib().rihip_ip_index_save(self.index._h, str(save_path).encode()), "ip_index_save")
+        if format == "faiss":
+            from . import faiss_io
+            if self.index.is_ivf:
+                faiss_io.write_ivf_flat(str(save_path), self.reconstruct(), self.centroids(), self.list_assignment(),
+                                        self.n_probe)
+            else:
+                faiss_io.write_flat(str(save_path), self.reconstruct())
+        elif format == "rihip":
+            L.check(L.lib().rihip_ip_index_save(self.index._h, str(save_path).encode()), "ip_index_save")
+        else:
+            raise ValueError(f"unknown index file format {format!r}")
         meta_path = save_path.with_suffix(".meta.pkl")
         with open(meta_path, "wb") as f:
             pickle.dump(
@@ -236,6 +250,22 @@ class FAISSIndex:
         with open(meta_path, "rb") as f:
             meta = pickle.load(f)  # sidecar written by save() above
         obj = cls(embed_dim=meta["embed_dim"], n_lists=meta["n_lists"], n_probe=meta["n_probe"])
+        from . import faiss_io
+        if faiss_io.sniff(str(load_path)) == "faiss":        # written by faiss.write_index (or save(format="faiss"))
+            f = faiss_io.read_index(str(load_path))
+            if f["metric"] != faiss_io.METRIC_INNER_PRODUCT:
+                raise ValueError("only METRIC_INNER_PRODUCT indexes are supported (faiss_index.py:70-72)")
+            assert f["d"] == obj.embed_dim, (f["d"], obj.embed_dim)
+            obj.exact = f["kind"] == "flat"
+            x_dev = torch.from_numpy(f["vectors"]).to(L.device())
+            ids = np.asarray(meta["item_ids"], dtype=np.int64)
+            if obj.exact:
+                obj.build_from_device(x_dev, ids)
+            else:
+                obj.n_lists = f["nlist"]
+                obj.build_from_device(x_dev, ids, centroids=f["centroids"], assign=f["assign"])
+            obj._item_id_to_faiss_idx = meta["item_id_to_faiss_idx"]
+            return obj
         h = C.c_void_p()
         L.check(L.lib().rihip_ip_index_load(str(load_path).encode(), C.byref(h)), "ip_index_load")
         obj.index = _IndexHandle(h.value, obj)

@@ -210,3 +210,50 @@ def test_ivf_underfill_not_masked_by_list_padding():
     Q = R.normalize_rows(-m + 0.2 * fx.unit_rows(rng, 8, d))   # negative scores against every list
     sc, rows, o_s, o_r = _compare_search(idx, Q, X, nprobe, k, min_checked=0.5)
     assert (rows >= 0).all() and (sc < 0).all()
+
+
+def test_faiss_file_interop(tmp_path):
+    """§8f-3: (a) an index trained here, written as a FAISS IndexIVFFlat file and read back, searches identically;
+    (b) a 'foreign' IndexIVFFlat file (centroids / lists not produced by this library's trainer) is loaded with ITS
+    partition and searched like the oracle; (c) flat indexes likewise.  Byte layout restated from faiss 1.7.x (parity
+    unpinned: faiss is not importable here, the reference ships no index file)."""
+    import pickle
+    from recommendit_amd import FAISSIndex, faiss_io
+    rng = np.random.RandomState(40)
+    N, d, nlist, nprobe, k = 30000, 64, 40, 6, 100
+    X = _clustered(rng, N, d, 20)
+    Q = fx.unit_rows(rng, 60, d)
+    ids = list(range(500, 500 + N))
+    idx = FAISSIndex(embed_dim=d, n_lists=nlist, n_probe=nprobe)
+    idx.build_ivf_index(X, ids)
+    s0, r0 = idx.batch_search(Q, k=k)
+    idx.save(str(tmp_path / "a.index"), format="faiss")
+    assert faiss_io.sniff(str(tmp_path / "a.index")) == "faiss"
+    back = FAISSIndex.load(str(tmp_path / "a.index"))
+    s1, r1 = back.batch_search(Q, k=k)
+    np.testing.assert_array_equal(r1, r0)
+    np.testing.assert_array_equal(s1, s0)
+    np.testing.assert_array_equal(back.list_assignment(), idx.list_assignment())
+    # (b) foreign file: NumPy k-means partition written in the FAISS layout + the reference's .meta.pkl sidecar
+    C = R.kmeans_ip(X, nlist, n_iter=3, seed=7)
+    a = R.ivf_assign(X, C)
+    Xn = R.normalize_rows(X)
+    faiss_io.write_ivf_flat(str(tmp_path / "b.index"), Xn, C, a, nprobe=3)
+    with open(tmp_path / "b.meta.pkl", "wb") as f:
+        pickle.dump({"item_ids": np.asarray(ids), "item_id_to_faiss_idx": {i: j for j, i in enumerate(ids)},
+                     "embed_dim": d, "n_lists": nlist, "n_probe": nprobe}, f)
+    fb = FAISSIndex.load(str(tmp_path / "b.index"))
+    assert fb.index.is_ivf and fb.index.ntotal == N and fb.n_probe == nprobe       # sidecar's nprobe wins (faiss_index.py:197)
+    np.testing.assert_array_equal(fb.list_assignment(), a)
+    np.testing.assert_array_equal(fb.centroids(), C)
+    sc, ids_got = fb.batch_search(Q, k=k)
+    o_s, o_r = R.ivf_search(R.normalize_rows(Q), Xn, C, a, nprobe, k)
+    np.testing.assert_allclose(sc, o_s, atol=TOL, rtol=0)
+    assert (ids_got == np.asarray(ids)[o_r]).mean() > 0.995                         # near-tie swaps only
+    # (c) flat
+    ex = FAISSIndex(embed_dim=d, exact=True)
+    ex.build_ivf_index(X, ids)
+    ex.save(str(tmp_path / "c.index"), format="faiss")
+    ex2 = FAISSIndex.load(str(tmp_path / "c.index"))
+    assert ex2.exact and not ex2.index.is_ivf
+    np.testing.assert_array_equal(ex2.batch_search(Q, k=k)[1], ex.batch_search(Q, k=k)[1])

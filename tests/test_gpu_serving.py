@@ -97,3 +97,48 @@ def test_batched_pipeline_matches_stagewise_oracle(tmp_path, kind, lists):
             assert np.allclose(np.sort(sc[qi]), np.sort(s[order]), atol=1e-12)
     one = pipe.get_recommendations(7, k=5)
     assert [r["item_id"] for r in one] == ids[1][:5].tolist() and one[0]["rank"] == 1
+
+
+def test_batched_run_evaluate_equals_per_user_protocol(tmp_path):
+    """recommendit_amd.evaluate.run_evaluate (one call per 256 users) against the reference's per-user loop
+    (run_pipeline.py:166-227) driven through the single-request entry and scored by the oracle metrics."""
+    from oracle import metrics_np as M
+    from recommendit_amd import FAISSIndex, LightGBMRanker, TwoTowerModel
+    from recommendit_amd.evaluate import run_evaluate
+    from recommendit_amd.recommender import GpuFeatureStore, GpuRecommendationPipeline, feature_columns
+    from recommendit_amd.synthetic import ml1m_like
+    ratings, movies, gm = ml1m_like(n_users=300, n_item_ids=420, n_catalog=400, n_ratings=30000, seed=2)
+    nu, ni, d = 300, 420, 64
+    torch.manual_seed(0)
+    model = TwoTowerModel(nu, ni, d, 128)
+    item_ids = sorted(movies["item_id"].unique().tolist())
+    E = model.get_item_embeddings(item_ids, gm[item_ids])
+    index = FAISSIndex(embed_dim=d, n_lists=8, n_probe=3)
+    index.build_ivf_index(E, item_ids)
+    forest = G.random_forest_model(30, 15, 50, seed=9, names=feature_columns())
+    p = tmp_path / "r.lgbm"
+    p.write_text(G.write_text_model(forest))
+    ranker = LightGBMRanker.load(str(p))
+    rng = np.random.RandomState(1)
+    store = GpuFeatureStore(nu, ni)
+    ut = store.user.copy(); it = store.item.copy()
+    ut[1:, :6] = rng.rand(nu, 6); ut[1:, 6:] = rng.rand(nu, 18)
+    it[1:, :5] = rng.rand(ni, 5); it[1:, 5:] = gm[1:]
+    store.load_arrays(ut, it)
+    pipe = GpuRecommendationPipeline(model, index, ranker, store, top_k_candidates=100, top_k_results=20)
+    res = run_evaluate(pipe, ratings, movies, n_eval_users=120, batch_size=50)
+    # the reference's loop, one user at a time
+    rs = ratings.sort_values("timestamp")
+    n_test = max(1, int(len(rs) * 0.1 / rs["user_id"].nunique()))
+    test = rs.groupby("user_id").tail(n_test)
+    recs, truth = {}, {}
+    for u in test["user_id"].unique()[:120]:
+        gt = test[(test["user_id"] == u) & (test["rating"] >= 4)]["item_id"].tolist()
+        truth[int(u)] = gt
+        if not gt:
+            continue
+        recs[int(u)] = [r["item_id"] for r in pipe.get_recommendations(int(u), k=20)]
+    assert res["n_eval_users"] == len(recs) > 50
+    for k in (5, 10, 20):
+        assert abs(res[f"ndcg@{k}"] - M.mean_ndcg(recs, truth, k)) < 1e-12
+    assert 0 < res["coverage"] <= 1

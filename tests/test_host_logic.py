@@ -146,3 +146,47 @@ def test_feature_store_parquet_loader_matches_row_by_row_path(tmp_path):
     st2 = GpuFeatureStore(3, 3)
     st2.load_all_features(pd.DataFrame({"user_id": [9], "avg_rating": [4.5], "genre_pref": [list(range(18))]}), None)
     assert st2.user.shape[0] == 10 and st2.user[9, 0] == 4.5 and st2.user[9, 6 + 17] == 17.0 and st2.user[5, 0] == 3.5
+
+
+def test_faiss_io_roundtrip_and_hand_assembled_bytes(tmp_path):
+    """recommendit_amd/faiss_io.py: writer -> reader round trip (full and sparse list tables) and a byte string
+    assembled by hand from the published layout of faiss 1.7.x index_write.cpp (parity unpinned: no faiss here)."""
+    import struct
+    from recommendit_amd import faiss_io as F
+    rng = np.random.RandomState(0)
+    d, n, nlist = 8, 50, 6
+    X = rng.randn(n, d).astype(np.float32)
+    C = rng.randn(nlist, d).astype(np.float32)
+    a = rng.randint(0, nlist, n).astype(np.int32)
+    for assign in (a, np.where(a < 2, a, 0).astype(np.int32)):            # second: 2 of 6 lists non-empty -> "sprs"
+        p = tmp_path / "i.faiss"
+        F.write_ivf_flat(str(p), X, C, assign, nprobe=3)
+        assert F.sniff(str(p)) == "faiss"
+        r = F.read_index(str(p))
+        assert (r["kind"], r["d"], r["ntotal"], r["nlist"], r["nprobe"], r["metric"]) == ("ivf", d, n, nlist, 3, 0)
+        np.testing.assert_array_equal(r["vectors"], X)
+        np.testing.assert_array_equal(r["centroids"], C)
+        np.testing.assert_array_equal(r["assign"], assign)
+    F.write_flat(str(tmp_path / "f.faiss"), X)
+    r = F.read_index(str(tmp_path / "f.faiss"))
+    assert r["kind"] == "flat"
+    np.testing.assert_array_equal(r["vectors"], X)
+    # hand-assembled IndexIVFFlat: d=2, 3 vectors, 2 lists (list 1 holds ids 2,0; list 0 holds id 1), array direct map
+    hdr = lambda d_, nt: struct.pack("<iqqq?i", d_, nt, 1 << 20, 1 << 20, True, 0)
+    cent = np.array([[1, 0], [0, 1]], np.float32)
+    vec = np.array([[0.1, 0.9], [0.8, 0.2], [0.3, 0.7]], np.float32)
+    blob = (b"IwFl" + hdr(2, 3) + struct.pack("<QQ", 2, 1)
+            + b"IxFI" + hdr(2, 2) + struct.pack("<Q", 4) + cent.tobytes()
+            + struct.pack("<b", 1) + struct.pack("<Q", 3) + np.array([5, 6, 7], np.int64).tobytes()
+            + b"ilar" + struct.pack("<QQ", 2, 8) + b"full" + struct.pack("<Q", 2) + np.array([1, 2], np.uint64).tobytes()
+            + vec[[1]].tobytes() + np.array([1], np.int64).tobytes()
+            + vec[[2, 0]].tobytes() + np.array([2, 0], np.int64).tobytes())
+    (tmp_path / "h.faiss").write_bytes(blob)
+    r = F.read_index(str(tmp_path / "h.faiss"))
+    np.testing.assert_array_equal(r["vectors"], vec)
+    np.testing.assert_array_equal(r["assign"], [1, 0, 1])
+    np.testing.assert_array_equal(r["centroids"], cent)
+    with pytest.raises(F.FaissFormatError):
+        (tmp_path / "t.faiss").write_bytes(blob[:-5]); F.read_index(str(tmp_path / "t.faiss"))
+    (tmp_path / "x.bin").write_bytes(b"RIHIPIDX" + b"\0" * 64)
+    assert F.sniff(str(tmp_path / "x.bin")) == "rihip"
