@@ -43,28 +43,29 @@ struct IpIndex {
   int64_t Np = 0;              // padded physical rows
   float* C = nullptr;          // [nlist,d]
   int* tile_list = nullptr;    // [Np/64] list of each granule
-  int* tile_nvalid = nullptr;  // [Np/32] real (non-padding) rows of each 32-row scan tile
+  int64_t* list_poff = nullptr; // [nlist+1] first physical row of each list (device)
+  int* list_len_dev = nullptr;  // [nlist] real rows of each list (device)
   int64_t* row_ids = nullptr;  // [Np] original row per physical row, -1 for padding
   std::vector<int64_t> list_len;  // host copy
   // scratch (grown on demand, owned by the handle)
   DevBuf<uint64_t> cand, scand, fcand;
   DevBuf<int> count, fail_flags, fail_list, n_fail, fcount;
   DevBuf<float> thr, thr2, fQ;
-  DevBuf<uint32_t> probe_bits;
-  DevBuf<int> blk_tiles, blk_ntiles;
+  DevBuf<float> coarse;                                    // IVF: coarse scores [nq,nlist]
+  DevBuf<int> probe_list, list_q, list_cnt, list_qoff, list_cur, work_off, plan;
   int* h_nfail = nullptr;  // pinned
 };
 
 inline void free_index_arrays(IpIndex* h) {
-  hipFree(h->X); hipFree(h->C); hipFree(h->tile_list); hipFree(h->tile_nvalid); hipFree(h->row_ids); hipFree(h->Xb);
-  h->X = nullptr; h->C = nullptr; h->tile_list = nullptr; h->tile_nvalid = nullptr; h->row_ids = nullptr; h->Xb = nullptr;
+  hipFree(h->X); hipFree(h->C); hipFree(h->tile_list); hipFree(h->list_poff); hipFree(h->list_len_dev); hipFree(h->row_ids); hipFree(h->Xb);
+  h->X = nullptr; h->C = nullptr; h->tile_list = nullptr; h->list_poff = nullptr; h->list_len_dev = nullptr; h->row_ids = nullptr; h->Xb = nullptr;
   h->N = 0; h->Np = 0; h->ivf = false; h->nlist = 0; h->list_len.clear();
 }
 
 // flat index: (re)build the bf16 filter copy and the row-norm bound (topk.hip)
 int prepare_flat(IpIndex* h, hipStream_t st);
-// (re)derive tile_nvalid from row_ids after the lists were laid out or loaded (ivf.hip)
-int derive_tile_nvalid(IpIndex* h, hipStream_t st);
+// upload the per-list offsets/lengths the list-major scan reads (from the host copy list_len; ivf.hip)
+int derive_ivf_aux(IpIndex* h, hipStream_t st);
 
 }  // namespace rihip_index
 

@@ -160,17 +160,6 @@ __global__ __launch_bounds__(256) void ivf_permute_kernel(const float* __restric
   if (c4 == 0) row_ids[p] = rid;
 }
 
-__global__ void tile_nvalid_kernel(const int64_t* __restrict__ row_ids, int64_t Np, int* nvalid) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t * TRS >= Np) return;
-  int n = 0;
-  for (int r = 0; r < TRS; ++r) {
-    const int64_t p = t * TRS + r;
-    if (p < Np && row_ids[p] >= 0) ++n;
-  }
-  nvalid[t] = n;
-}
-
 // original-order rows out of the list-ordered corpus
 __global__ void ivf_unpermute_kernel(const float* __restrict__ Xn, int d, const int64_t* __restrict__ row_ids, int64_t Np,
                                      float* X) {
@@ -280,7 +269,7 @@ int build_lists(IpIndex* h, int nlist, float* C, Grouper& g, hipStream_t st) {
   hipFree(h->Xb);  // the IVF scan never reads the bf16 filter copy
   h->Xb = nullptr;
   h->X = Xn; h->Np = Np; h->nlist = nlist; h->ivf = true; h->C = C;
-  return derive_tile_nvalid(h, st);
+  return derive_ivf_aux(h, st);
 }
 
 int train_impl(IpIndex* h, int nlist, int n_iter, float* C /*device, initial centroids; owned*/, const int* assign_given,
@@ -299,8 +288,8 @@ int train_impl(IpIndex* h, int nlist, int n_iter, float* C /*device, initial cen
   hipFree(assign);
   if (rc != RIHIP_OK) {  // leave a usable flat index behind
     hipFree(C);
-    hipFree(h->row_ids); hipFree(h->tile_list); hipFree(h->tile_nvalid);
-    h->row_ids = nullptr; h->tile_list = nullptr; h->tile_nvalid = nullptr; h->C = nullptr;
+    hipFree(h->row_ids); hipFree(h->tile_list); hipFree(h->list_poff); hipFree(h->list_len_dev);
+    h->row_ids = nullptr; h->tile_list = nullptr; h->list_poff = nullptr; h->list_len_dev = nullptr; h->C = nullptr;
   }
   return rc;
 }
@@ -316,13 +305,20 @@ int check_trainable(IpIndex* h, int nlist, const char* what) {
 }  // namespace
 
 namespace rihip_index {
-int derive_tile_nvalid(IpIndex* h, hipStream_t st) {
-  const int64_t nt = (h->Np + TRS - 1) / TRS;
-  hipFree(h->tile_nvalid);
-  h->tile_nvalid = nullptr;
-  HIPCHK(hipMalloc((void**)&h->tile_nvalid, sizeof(int) * nt));
-  hipLaunchKernelGGL(tile_nvalid_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, h->row_ids, h->Np, h->tile_nvalid);
-  RIHIP_CHECK_LAUNCH();
+int derive_ivf_aux(IpIndex* h, hipStream_t st) {
+  const int nlist = h->nlist;
+  std::vector<int64_t> poff(nlist + 1, 0);
+  std::vector<int> len(nlist, 0);
+  for (int c = 0; c < nlist; ++c) {
+    len[c] = (int)h->list_len[c];
+    poff[c + 1] = poff[c] + (h->list_len[c] + TR - 1) / TR * TR;
+  }
+  hipFree(h->list_poff); hipFree(h->list_len_dev);
+  h->list_poff = nullptr; h->list_len_dev = nullptr;
+  HIPCHK(hipMalloc((void**)&h->list_poff, sizeof(int64_t) * (nlist + 1)));
+  HIPCHK(hipMalloc((void**)&h->list_len_dev, sizeof(int) * (nlist > 0 ? nlist : 1)));
+  HIPCHK(hipMemcpyAsync(h->list_poff, poff.data(), sizeof(int64_t) * (nlist + 1), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(h->list_len_dev, len.data(), sizeof(int) * nlist, hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));
   return RIHIP_OK;
 }
@@ -488,7 +484,7 @@ extern "C" int rihip_ip_index_load(const char* path, void** handle) {
                  hipMemcpy(h->C, C.data(), sizeof(float) * C.size(), hipMemcpyHostToDevice) == hipSuccess &&
                  hipMemcpy(h->tile_list, tl.data(), sizeof(int) * tl.size(), hipMemcpyHostToDevice) == hipSuccess &&
                  hipMemcpy(h->row_ids, rid.data(), sizeof(int64_t) * rid.size(), hipMemcpyHostToDevice) == hipSuccess;
-    if (ok) ok = derive_tile_nvalid(h, 0) == RIHIP_OK;
+    if (ok) ok = derive_ivf_aux(h, 0) == RIHIP_OK;
   }
   if (ok && !h->ivf) ok = prepare_flat(h, 0) == RIHIP_OK;
   fclose(f);

@@ -59,16 +59,6 @@ struct ScanArgs {
   int* count;            // [nq]
   int nsplit;            // splits of the tile sequence (gridDim.y)
   int dense;             // 1: slot = virtual row (no atomics, count preset); 0: atomic append
-  // IVF (all null/0 for brute force)
-  const int* tile_list;       // [n_virtual/64] list id of each 64-row granule
-  const uint32_t* probe_bits; // [nq, pb_words] bitset of probed lists
-  int pb_words;
-  const int64_t* row_ids;     // [N] original row id per physical row (IVF), or null
-  const int* tile_nvalid;     // [n_scan_tiles] real rows of each 32-row tile (list padding sits at the tile's end), or null
-  const int* blk_tiles;       // [query blocks, n_scan_tiles] 32-row tiles some query of the block probes
-  const int* blk_ntiles;      // [query blocks]
-  int64_t n_scan_tiles;
-  int tile_step;              // IVF threshold sample: visit every tile_step-th tile of the block list (0/1 = all)
   int qgrid;                  // bf16 filter: number of query blocks (1-D XCD-aware launch)
 };
 
@@ -93,18 +83,15 @@ __global__ __launch_bounds__(256, 2) void scan_kernel(ScanArgs a) {
   for (int kb = 0; kb < KB; ++kb) qf[kb] = *reinterpret_cast<const f32x4*>(&a.Q[qrow * D + kb * 8 + 4 * hh]);
   const float thr = (a.thr && q_ok) ? a.thr[q] : -INFINITY;
   uint64_t* my_cand = a.cand + (size_t)qrow * a.cap;
-  const uint32_t* my_bits = a.probe_bits ? a.probe_bits + (size_t)qrow * a.pb_words : nullptr;
 
-  const int* tl = a.blk_tiles ? a.blk_tiles + (size_t)blockIdx.x * a.n_scan_tiles : nullptr;
-  const int tstep = (a.blk_tiles && a.tile_step > 1) ? a.tile_step : 1;
-  const int64_t n_seq = a.blk_tiles ? ((int64_t)a.blk_ntiles[blockIdx.x] + tstep - 1) / tstep : (a.n_virtual + TRS - 1) / TRS;
+  const int64_t n_seq = (a.n_virtual + TRS - 1) / TRS;
   const int64_t per = (n_seq + a.nsplit - 1) / a.nsplit;
   const int64_t i0 = (int64_t)blockIdx.y * per;
   const int64_t i1 = (i0 + per < n_seq) ? i0 + per : n_seq;
   if (i0 >= i1) return;  // uniform across the workgroup
 
   f32x4 stage[NV];
-  auto tile_at = [&](int64_t i) -> int64_t { return tl ? (int64_t)tl[i * tstep] : i; };
+  auto tile_at = [&](int64_t i) -> int64_t { return i; };
   auto load_tile = [&](int64_t tile) {
     const int64_t v_base = tile * TRS;
 #pragma unroll
@@ -137,12 +124,7 @@ __global__ __launch_bounds__(256, 2) void scan_kernel(ScanArgs a) {
       }
       return;
     }
-    if (my_bits) {  // IVF: only queries that probe this tile's list take its rows
-      const int L = a.tile_list[tile >> 1];
-      if (!((my_bits[L >> 5] >> (L & 31)) & 1u)) return;
-    }
-    // list padding rows are never candidates (they would inflate count[q] and mask an under-filled list)
-    const int n_ok = a.tile_nvalid ? a.tile_nvalid[tile] : ((a.n_virtual - v_base) < TRS ? (int)(a.n_virtual - v_base) : TRS);
+    const int n_ok = (a.n_virtual - v_base) < TRS ? (int)(a.n_virtual - v_base) : TRS;
     unsigned hits = 0;  // per-lane aggregation: one atomic per (query, tile) that has survivors
 #pragma unroll
     for (int r = 0; r < 16; ++r)
@@ -153,9 +135,7 @@ __global__ __launch_bounds__(256, 2) void scan_kernel(ScanArgs a) {
       for (int r = 0; r < 16; ++r) {
         if (hits & (1u << r)) {
           const int64_t v = v_base + acc_row(r, lane);
-          const int64_t rid = a.row_ids ? a.row_ids[v] : v;
-          // padding rows (rid<0) keep their slot with the lowest key so counts stay consistent
-          if (pos < a.cap) my_cand[pos] = (rid >= 0) ? make_key(acc[r], (uint32_t)rid) : 0ull;
+          if (pos < a.cap) my_cand[pos] = make_key(acc[r], (uint32_t)v);
           ++pos;
         }
       }
@@ -194,39 +174,6 @@ __global__ __launch_bounds__(256, 2) void scan_kernel(ScanArgs a) {
     if (has_pre) store_tile(pre);
     st = sn;
     __syncthreads();
-  }
-}
-
-// IVF: per query block, the ascending list of 32-row tiles whose list some query of the block probes
-__global__ __launch_bounds__(256) void ivf_block_tiles_kernel(const uint32_t* __restrict__ probe_bits, int pb_words,
-                                                              int64_t nq, const int* __restrict__ tile_list,
-                                                              int64_t n_scan_tiles, int* blk_tiles, int* blk_ntiles) {
-  __shared__ uint32_t bits[64];
-  const int tid = threadIdx.x;
-  if (tid < 64) bits[tid] = 0u;
-  __syncthreads();
-  const int64_t q0 = (int64_t)blockIdx.x * QB;
-  for (int i = tid; i < QB * pb_words; i += 256) {
-    const int64_t q = q0 + i / pb_words;
-    if (q < nq) atomicOr(&bits[i % pb_words], probe_bits[q * pb_words + (i % pb_words)]);
-  }
-  __syncthreads();
-  int* out = blk_tiles + (size_t)blockIdx.x * n_scan_tiles;
-  // wave 0 compacts in order (ballot prefix), 64 tiles per step
-  if (tid < 64) {
-    int base = 0;
-    for (int64_t t0 = 0; t0 < n_scan_tiles; t0 += 64) {
-      const int64_t t = t0 + tid;
-      bool on = false;
-      if (t < n_scan_tiles) {
-        const int L = tile_list[t >> 1];
-        on = (bits[L >> 5] >> (L & 31)) & 1u;
-      }
-      const unsigned long long m = __ballot(on);
-      if (on) out[base + __popcll(m & ((1ull << tid) - 1ull))] = (int)t;
-      base += __popcll(m);
-    }
-    if (tid == 0) blk_ntiles[blockIdx.x] = base;
   }
 }
 
@@ -652,26 +599,92 @@ __global__ void map_rows_kernel(int64_t* rows, int64_t n, const int64_t* __restr
   if (i < n) { const int64_t r = rows[i]; rows[i] = (r >= 0) ? ids[r] : -1; }
 }
 
-// coarse quantizer: top-nprobe lists per query by IP -> probe bitset (one wave per query)
-__global__ __launch_bounds__(256) void ivf_probe_kernel(const float* __restrict__ Q, int64_t nq, int d,
-                                                        const float* __restrict__ C, int nlist, int nprobe,
-                                                        uint32_t* bits, int pb_words) {
+// ------------------------------- IVF search: list-major scan ------------------------------------
+// faiss IndexIVFFlat.search (reference src/models/faiss_index.py:113,:145): coarse top-nprobe lists per query by inner
+// product with the centroids, then an exact scan of the probed lists only.  Batched the list-major way: the
+// (query, probed list) pairs are grouped by LIST, and every wave takes (one list, 32 of the queries that probe it,
+// a range of the list's 32-row tiles): the 32 queries sit in registers (MFMA B operand), the tile rows are loaded
+// straight into the MFMA A-operand registers (no LDS, no barrier: waves are independent, the plan decides how many of
+// them a list gets), exact-f32 MFMA, scores >= thr[q] appended to the query's candidate list.  Work = nprobe/nlist of
+// the brute force, whatever the batch size; rows of a list are re-read by its query groups from L2.
+struct LmArgs {
+  const float* X;            // [Np,d] list-ordered corpus
+  const float* Q;            // [nq,d]
+  const float* thr;          // [nq] or null (every probed row is a candidate)
+  uint64_t* cand;            // [nq, cap]
+  int64_t cap;
+  int* count;                // [nq]
+  const int64_t* row_ids;    // [Np] original row of each physical row
+  const int64_t* list_poff;  // [nlist+1] first physical row of each list (multiples of 64)
+  const int* list_len;       // [nlist] real rows of each list
+  const int* list_qoff;      // [nlist+1] first slot of each list in list_q
+  const int* list_q;         // [nq*nprobe] query indices grouped by list
+  const int* work_off;       // [nlist+1] first work item of each list
+  const int* plan;           // [0] = number of work items, [1] = tile splits per (list, query group)
+  int nlist;
+  int tile_step;             // visit every tile_step-th tile of a list (threshold sample), 1 = all
+};
+
+// coarse scores cs[q, c] = <Q[q], C[c]> on exact-f32 MFMA (4 waves x 32 register-stationary queries, centroid tiles
+// of 32 through LDS) -- the IndexFlatIP quantizer
+template <int D>
+__global__ __launch_bounds__(256, 2) void ivf_coarse_kernel(const float* __restrict__ Q, int64_t nq,
+                                                            const float* __restrict__ C, int nlist, float* cs) {
+  constexpr int LDC = D + 4, KB = D / 8;
+  constexpr int NV = (32 * (D / 4) + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float Cs[32 * LDC];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r31 = lane & 31, hh = lane >> 5;
+  const int64_t q = (int64_t)blockIdx.x * 128 + w * 32 + r31;
+  const int64_t qc = q < nq ? q : nq - 1;
+  f32x4 xr[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) xr[kb] = *reinterpret_cast<const f32x4*>(&Q[qc * D + kb * 8 + 4 * hh]);
+  const int ntile = (nlist + 31) / 32;
+  for (int t = 0; t < ntile; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * 256;
+      const int r = idx / (D / 4), c4 = idx % (D / 4);
+      if (idx < 32 * (D / 4)) {
+        const int c = t * 32 + r;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c < nlist) v = reinterpret_cast<const f32x4*>(C + (size_t)c * D)[c4];
+        *reinterpret_cast<f32x4*>(&Cs[r * LDC + c4 * 4]) = v;
+      }
+    }
+    __syncthreads();
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const f32x4 av = *reinterpret_cast<const f32x4*>(&Cs[r31 * LDC + kb * 8 + 4 * hh]);
+      acc = mfma32(av.x, xr[kb].x, acc);
+      acc = mfma32(av.y, xr[kb].y, acc);
+      acc = mfma32(av.z, xr[kb].z, acc);
+      acc = mfma32(av.w, xr[kb].w, acc);
+    }
+    if (q < nq) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = t * 32 + acc_row(r, lane);
+        if (c < nlist) cs[(size_t)q * nlist + c] = acc[r];
+      }
+    }
+  }
+}
+
+// top-nprobe lists of each query (ties -> lowest list id), one wave per query; counts the probes of every list
+__global__ __launch_bounds__(256) void ivf_select_kernel(const float* __restrict__ cs, int64_t nq, int nlist, int nprobe,
+                                                         int* probe_list, int* list_cnt) {
   extern __shared__ float sc[];  // [4][nlist]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t q = (int64_t)blockIdx.x * 4 + w;
   if (q >= nq) return;
   float* my = sc + (size_t)w * nlist;
-  for (int c = 0; c < nlist; ++c) {
-    float s = 0.f;
-    for (int k = lane; k < d; k += 64) s += Q[q * d + k] * C[c * d + k];
-    s = wave_sum(s);
-    if (lane == 0) my[c] = s;
-  }
+  for (int c = lane; c < nlist; c += 64) my[c] = cs[(size_t)q * nlist + c];
   __builtin_amdgcn_wave_barrier();
-  for (int i = lane; i < pb_words; i += 64) bits[(size_t)q * pb_words + i] = 0u;
-  __builtin_amdgcn_wave_barrier();
-  // nprobe rounds of argmax (ties -> lowest list id)
-  for (int p = 0; p < nprobe && p < nlist; ++p) {
+  for (int p = 0; p < nprobe; ++p) {
     float best = -INFINITY;
     int bi = 0x7fffffff;
     for (int c = lane; c < nlist; c += 64) {
@@ -684,11 +697,159 @@ __global__ __launch_bounds__(256) void ivf_probe_kernel(const float* __restrict_
       const int oi = __shfl_xor(bi, o, 64);
       if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
-    if (lane == 0 && bi != 0x7fffffff) {
-      bits[(size_t)q * pb_words + (bi >> 5)] |= (1u << (bi & 31));
-      my[bi] = -INFINITY;
+    if (bi == 0x7fffffff) bi = -1;  // fewer than nprobe lists (or only NaN scores left)
+    if (lane == 0) {
+      probe_list[(size_t)q * nprobe + p] = bi;
+      if (bi >= 0) { atomicAdd(&list_cnt[bi], 1); my[bi] = -INFINITY; }
     }
     __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// one workgroup: slot offsets of the lists, the tile split and the work-item offsets; zeroes the candidate counters
+__global__ __launch_bounds__(256) void ivf_plan_kernel(const int* __restrict__ list_cnt, const int64_t* __restrict__ list_poff,
+                                                       int nlist, int tile_step, int target_items, int* list_qoff,
+                                                       int* list_cur, int* work_off, int* plan, int* count, int64_t nq) {
+  __shared__ int part[256];
+  __shared__ int s_total;
+  const int tid = threadIdx.x;
+  const int per = (nlist + 255) / 256;
+  const int c0 = tid * per, c1 = (c0 + per < nlist) ? c0 + per : nlist;
+  for (int64_t i = tid; i < nq; i += 256) count[i] = 0;
+  auto block_excl = [&](int mine) -> int {  // exclusive prefix of `mine` over the threads; s_total = sum
+    part[tid] = mine;
+    __syncthreads();
+    if (tid == 0) {
+      int run = 0;
+      for (int i = 0; i < 256; ++i) { const int v = part[i]; part[i] = run; run += v; }
+      s_total = run;
+    }
+    __syncthreads();
+    const int out = part[tid];
+    __syncthreads();
+    return out;
+  };
+  // pass 1: slots (queries per list) and the number of (list, 32-query group) pairs
+  int m_sum = 0, g_sum = 0;
+  for (int c = c0; c < c1; ++c) { m_sum += list_cnt[c]; g_sum += (list_cnt[c] + 31) / 32; }
+  int q_off = block_excl(m_sum);
+  const int m_total = s_total;
+  (void)block_excl(g_sum);
+  const int n_lg = s_total;
+  int S = n_lg > 0 ? (target_items + n_lg - 1) / n_lg : 1;
+  if (S < 1) S = 1;
+  // pass 2: work items
+  int w_sum = 0;
+  for (int c = c0; c < c1; ++c) {
+    const int64_t tiles = (list_poff[c + 1] - list_poff[c]) / TRS;
+    const int64_t n_seq = (tiles + tile_step - 1) / tile_step;
+    const int s_c = (int)(n_seq < S ? n_seq : S);
+    w_sum += ((list_cnt[c] + 31) / 32) * s_c;
+  }
+  int w_off = block_excl(w_sum);
+  const int n_work = s_total;
+  for (int c = c0; c < c1; ++c) {
+    list_qoff[c] = q_off; list_cur[c] = q_off; work_off[c] = w_off;
+    q_off += list_cnt[c];
+    const int64_t tiles = (list_poff[c + 1] - list_poff[c]) / TRS;
+    const int64_t n_seq = (tiles + tile_step - 1) / tile_step;
+    const int s_c = (int)(n_seq < S ? n_seq : S);
+    w_off += ((list_cnt[c] + 31) / 32) * s_c;
+  }
+  if (tid == 0) { list_qoff[nlist] = m_total; work_off[nlist] = n_work; plan[0] = n_work; plan[1] = S; }
+}
+
+__global__ void ivf_scatter_kernel(const int* __restrict__ probe_list, int64_t n_pairs, int nprobe, int* list_cur, int* list_q) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pairs) return;
+  const int c = probe_list[i];
+  if (c >= 0) list_q[atomicAdd(&list_cur[c], 1)] = (int)(i / nprobe);
+}
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void ivf_scan_lm_kernel(LmArgs a) {
+  constexpr int KB = D / 8;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r31 = lane & 31, hh = lane >> 5;
+  const int wi = blockIdx.x * 4 + w;
+  if (wi >= a.plan[0]) return;  // wave-uniform
+  // which list: largest c with work_off[c] <= wi
+  int lo = 0, hi = a.nlist;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (a.work_off[mid] <= wi) lo = mid; else hi = mid;
+  }
+  const int c = lo;
+  const int rem = wi - a.work_off[c];
+  const int64_t p0 = a.list_poff[c];
+  const int64_t tiles = (a.list_poff[c + 1] - p0) / TRS;
+  const int tstep = a.tile_step > 1 ? a.tile_step : 1;
+  const int64_t n_seq = (tiles + tstep - 1) / tstep;
+  const int S = a.plan[1];
+  const int s_c = (int)(n_seq < S ? n_seq : S);
+  const int grp = rem / s_c, split = rem % s_c;
+  const int q0 = a.list_qoff[c], m = a.list_qoff[c + 1] - q0;
+  const int slot = grp * 32 + r31;
+  const bool q_ok = slot < m;
+  const int64_t q = a.list_q[q0 + (q_ok ? slot : grp * 32)];
+  const int len = a.list_len[c];
+  f32x4 qf[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) qf[kb] = *reinterpret_cast<const f32x4*>(&a.Q[q * D + kb * 8 + 4 * hh]);
+  const float thr = a.thr ? a.thr[q] : -INFINITY;
+  uint64_t* my_cand = a.cand + (size_t)q * a.cap;
+  const int64_t per = (n_seq + s_c - 1) / s_c;
+  const int64_t i0 = (int64_t)split * per;
+  const int64_t i1 = (i0 + per < n_seq) ? i0 + per : n_seq;
+  if (i0 >= i1) return;
+
+  f32x4 xa[KB], xb[KB];
+  auto load_tile = [&](f32x4* dst, int64_t i) {
+    const float* row = a.X + (size_t)(p0 + i * tstep * TRS + r31) * D + 4 * hh;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) dst[kb] = *reinterpret_cast<const f32x4*>(row + kb * 8);
+  };
+  auto chain = [&](const f32x4* x) -> f32x16 {
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      acc = mfma32(x[kb].x, qf[kb].x, acc);
+      acc = mfma32(x[kb].y, qf[kb].y, acc);
+      acc = mfma32(x[kb].z, qf[kb].z, acc);
+      acc = mfma32(x[kb].w, qf[kb].w, acc);
+    }
+    return acc;
+  };
+  auto emit = [&](const f32x16& acc, int64_t i) {
+    if (!q_ok) return;
+    const int64_t t_row0 = i * tstep * TRS;              // first row of the tile inside the list
+    const int64_t left = (int64_t)len - t_row0;           // list padding rows are never candidates
+    const int n_ok = left >= TRS ? TRS : (left > 0 ? (int)left : 0);
+    unsigned hits = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (acc_row(r, lane) < n_ok && acc[r] >= thr) hits |= (1u << r);
+    if (hits) {
+      int pos = atomicAdd(&a.count[q], __popc(hits));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (hits & (1u << r)) {
+          const int64_t v = p0 + t_row0 + acc_row(r, lane);
+          if (pos < a.cap) my_cand[pos] = make_key(acc[r], (uint32_t)a.row_ids[v]);
+          ++pos;
+        }
+      }
+    }
+  };
+  load_tile(xa, i0);
+#pragma unroll 1
+  for (int64_t i = i0; i < i1; i += 2) {
+    if (i + 1 < i1) load_tile(xb, i + 1);
+    emit(chain(xa), i);
+    if (i + 1 < i1) {
+      if (i + 2 < i1) load_tile(xa, i + 2);
+      emit(chain(xb), i + 1);
+    }
   }
 }
 
@@ -770,34 +931,48 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
     std::vector<int64_t> ll = h->list_len;
     std::sort(ll.begin(), ll.end(), [](int64_t x, int64_t y) { return x > y; });
     int64_t cap_full = 0;
-    for (int i = 0; i < h->nprobe && i < (int)ll.size(); ++i) cap_full += (ll[i] + TR - 1) / TR * TR;
+    for (int i = 0; i < h->nprobe && i < (int)ll.size(); ++i) cap_full += ll[i];
     if (cap_full < 1) cap_full = 1;
-    const int pbw = (h->nlist + 31) / 32;
-    RIHIP_REQUIRE(pbw <= 64, RIHIP_ERR_SHAPE, "ip_index: nlist=%d > 2048 unsupported", h->nlist);
-    const int64_t n_scan_tiles = (Nphys + TRS - 1) / TRS;
-    // one IVF pass over `n` queries: probe -> block tile lists -> scan (optionally thresholded / tile-sampled)
+    const int nlist = h->nlist;
+    const int nprobe = h->nprobe < nlist ? h->nprobe : nlist;
+    RIHIP_REQUIRE(nlist <= NLIST_MAX, RIHIP_ERR_SHAPE, "ip_index: nlist=%d > %d unsupported", nlist, NLIST_MAX);
+    // one IVF pass over `n` queries: plan (tile split for this sampling step) -> list-major scan
     auto ivf_scan = [&](const float* Qp, int64_t n, const float* thr, uint64_t* cand, int64_t cap, int tile_step) -> int {
-      const unsigned qg = (unsigned)((n + QB - 1) / QB);
-      ScanArgs x;
+      const int target = 16 * RIHIP_NCU;  // wave work items aimed at: 2 waves per SIMD on every CU, twice over
+      hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(256), 0, st, h->list_cnt.p, h->list_poff, nlist, tile_step, target,
+                         h->list_qoff.p, h->list_cur.p, h->work_off.p, h->plan.p, h->count.p, n);
+      LmArgs x;
       memset(&x, 0, sizeof(x));
-      x.X = h->X; x.Q = Qp; x.nq = n; x.count = h->count.p; x.n_virtual = Nphys; x.row_stride = 1; x.thr = thr;
-      x.cand = cand; x.cap = cap; x.dense = 0; x.tile_list = h->tile_list; x.probe_bits = h->probe_bits.p;
-      x.pb_words = pbw; x.row_ids = h->row_ids; x.tile_nvalid = h->tile_nvalid; x.blk_tiles = h->blk_tiles.p; x.blk_ntiles = h->blk_ntiles.p;
-      x.n_scan_tiles = n_scan_tiles; x.tile_step = tile_step;
-      const int64_t est = (n_scan_tiles * h->nprobe) / (h->nlist > 0 ? h->nlist : 1) / (tile_step > 1 ? tile_step : 1) + 1;
-      x.nsplit = pick_nsplit(n, est);
-      hipLaunchKernelGGL(fill_int_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->count.p, n, 0);
-      return dispatch_scan(d, x, dim3(qg, x.nsplit), st);
+      x.X = h->X; x.Q = Qp; x.thr = thr; x.cand = cand; x.cap = cap; x.count = h->count.p; x.row_ids = h->row_ids;
+      x.list_poff = h->list_poff; x.list_len = h->list_len_dev; x.list_qoff = h->list_qoff.p; x.list_q = h->list_q.p;
+      x.work_off = h->work_off.p; x.plan = h->plan.p; x.nlist = nlist; x.tile_step = tile_step;
+      // n_work <= target + #(list, query group) pairs <= target + nlist + n*nprobe/32
+      const int64_t bound = (int64_t)target + nlist + (n * nprobe + 31) / 32 + 4;
+      const dim3 grid((unsigned)((bound + 3) / 4));
+      if (d == 32) hipLaunchKernelGGL((ivf_scan_lm_kernel<32>), grid, dim3(256), 0, st, x);
+      else if (d == 64) hipLaunchKernelGGL((ivf_scan_lm_kernel<64>), grid, dim3(256), 0, st, x);
+      else hipLaunchKernelGGL((ivf_scan_lm_kernel<128>), grid, dim3(256), 0, st, x);
+      return check_launch("ivf scan");
     };
+    // coarse quantizer -> probed lists -> (query, list) pairs grouped by list
     auto ivf_prepare = [&](const float* Qp, int64_t n) -> int {
-      const unsigned qg = (unsigned)((n + QB - 1) / QB);
-      RCCHK(h->probe_bits.reserve(n * pbw));
-      RCCHK(h->blk_tiles.reserve((int64_t)qg * n_scan_tiles));
-      RCCHK(h->blk_ntiles.reserve(qg));
-      hipLaunchKernelGGL(ivf_probe_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), sizeof(float) * 4 * h->nlist, st, Qp,
-                         n, d, h->C, h->nlist, h->nprobe, h->probe_bits.p, pbw);
-      hipLaunchKernelGGL(ivf_block_tiles_kernel, dim3(qg), dim3(256), 0, st, h->probe_bits.p, pbw, n, h->tile_list,
-                         n_scan_tiles, h->blk_tiles.p, h->blk_ntiles.p);
+      RCCHK(h->coarse.reserve(n * nlist));
+      RCCHK(h->probe_list.reserve(n * nprobe));
+      RCCHK(h->list_q.reserve(n * nprobe));
+      RCCHK(h->list_cnt.reserve(nlist)); RCCHK(h->list_qoff.reserve(nlist + 1)); RCCHK(h->list_cur.reserve(nlist));
+      RCCHK(h->work_off.reserve(nlist + 1)); RCCHK(h->plan.reserve(2));
+      HIPCHK(hipMemsetAsync(h->list_cnt.p, 0, sizeof(int) * nlist, st));
+      const dim3 cg((unsigned)((n + 127) / 128));
+      if (d == 32) hipLaunchKernelGGL((ivf_coarse_kernel<32>), cg, dim3(256), 0, st, Qp, n, h->C, nlist, h->coarse.p);
+      else if (d == 64) hipLaunchKernelGGL((ivf_coarse_kernel<64>), cg, dim3(256), 0, st, Qp, n, h->C, nlist, h->coarse.p);
+      else hipLaunchKernelGGL((ivf_coarse_kernel<128>), cg, dim3(256), 0, st, Qp, n, h->C, nlist, h->coarse.p);
+      hipLaunchKernelGGL(ivf_select_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), sizeof(float) * 4 * nlist, st,
+                         h->coarse.p, n, nlist, nprobe, h->probe_list.p, h->list_cnt.p);
+      // slot offsets (the scan's own plan launch recomputes them together with its tile split)
+      hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(256), 0, st, h->list_cnt.p, h->list_poff, nlist, 1, 1,
+                         h->list_qoff.p, h->list_cur.p, h->work_off.p, h->plan.p, h->count.p, (int64_t)0);
+      hipLaunchKernelGGL(ivf_scatter_kernel, dim3((unsigned)((n * nprobe + 255) / 256)), dim3(256), 0, st, h->probe_list.p,
+                         n * nprobe, nprobe, h->list_cur.p, h->list_q.p);
       return check_launch("ivf prepare");
     };
     // unfiltered pass (every probed vector is a candidate): small populations and the exact fallback
@@ -1006,7 +1181,8 @@ extern "C" int rihip_ip_index_destroy(void* handle) {
   free_index_arrays(h);
   h->cand.release(); h->scand.release(); h->fcand.release(); h->count.release(); h->fail_flags.release();
   h->fail_list.release(); h->n_fail.release(); h->fcount.release(); h->thr.release(); h->thr2.release(); h->fQ.release();
-  h->probe_bits.release(); h->blk_tiles.release(); h->blk_ntiles.release(); h->qnorm.release();
+  h->coarse.release(); h->probe_list.release(); h->list_q.release(); h->list_cnt.release(); h->list_qoff.release();
+  h->list_cur.release(); h->work_off.release(); h->plan.release(); h->qnorm.release();
   if (h->h_nfail) hipHostFree(h->h_nfail);
   delete h;
   return RIHIP_OK;
