@@ -21,6 +21,7 @@
 #include <fstream>
 #include <sstream>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace {
@@ -71,7 +72,16 @@ struct Forest {
   std::vector<Node8> nodes8;
   std::vector<int> chunk8;  // [n_chunks8+1] tree starts
   Node8* d_nodes8 = nullptr; int* d_chunk8 = nullptr;
+  std::vector<int> depth8;   // per tree: longest root-to-leaf path (internal nodes visited)
+  int* d_depth8 = nullptr;
+  bool simple8 = false;      // every split has missing type None: NaN features are cleaned to 0 once per tile
   float zero_thr32 = 0.f;
+  // walk-ordered records (simple8 forests): see gbdt_walk_kernel
+  bool bfs = false;
+  std::vector<uint2> rec;            // per chunk: 8-byte records, chunk c at rec_chunk_off[c]
+  std::vector<int> rec_chunk_off;    // [n_chunks8+1] record index of each chunk's first record
+  std::vector<int> rec_root;         // per tree: byte offset of its root record inside its chunk
+  uint2* d_rec = nullptr; int* d_rec_chunk_off = nullptr; int* d_rec_root = nullptr;
 };
 
 struct PredArgs {
@@ -120,11 +130,16 @@ __global__ __launch_bounds__(256) void gbdt_predict_kernel(PredArgs a) {
     for (int i = tid; i < (n1 - n0) * 2; i += 256) dst[i] = src[i];
     for (int i = tid; i < (l1 - l0); i += 256) lS[i] = a.leaves[l0 + i];
   }
-  const int64_t row = (int64_t)blockIdx.x * 64 + lane;
-  for (int i = tid; i < 64 * a.F; i += 256) {
-    const int r = i / a.F, f = i % a.F;
-    const int64_t gr = (int64_t)blockIdx.x * 64 + r;
-    xS[f * 64 + r] = (gr < a.n) ? a.X[gr * a.ldx + f] : 0.f;
+  // the workgroup keeps its tree chunk in LDS and walks candidate tile after candidate tile through it: the forest is
+  // read gridDim.x times in all instead of once per 64 candidates (1.4 GB of L2 traffic per 128k candidates before)
+  const int64_t n_tiles = (a.n + 63) / 64;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  const int64_t row = tile * 64 + lane;
+  __syncthreads();   // previous tile's walks and reduction are done with xS / red
+  {  // lane = candidate, wave w takes features w, w+4, ...: conflict-free writes of the transposed tile
+    const int64_t gr = tile * 64 + lane;
+    const float* xr = a.X + (gr < a.n ? gr : 0) * a.ldx;
+    for (int f = w; f < a.F; f += 4) xS[f * 64 + lane] = (gr < a.n) ? xr[f] : 0.f;
   }
   __syncthreads();
   double acc = 0.0;
@@ -145,6 +160,7 @@ __global__ __launch_bounds__(256) void gbdt_predict_kernel(PredArgs a) {
   red[w][lane] = acc;
   __syncthreads();
   if (w == 0 && row < a.n) a.part[(size_t)chunk * a.n + row] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+  }
 }
 
 // Compact-forest traversal: 8-byte nodes, exact f32 comparisons, dynamic LDS sized to the forest chunk and the feature
@@ -152,11 +168,12 @@ __global__ __launch_bounds__(256) void gbdt_predict_kernel(PredArgs a) {
 // resident waves are what hides its latency).  Same per-wave tree order and same reduction as the general kernel.
 struct Pred8Args {
   const Node8* nodes; const double* leaves;
-  const int *tree_node_off, *tree_leaf_off, *tree_root, *chunk;
+  const int *tree_node_off, *tree_leaf_off, *tree_root, *chunk, *tree_depth;
   const float* X; int64_t n; int F; int ldx;
   float zero_thr;
   double* part;
 };
+template <bool SIMPLE>
 __global__ __launch_bounds__(256, 3) void gbdt_predict8_kernel(Pred8Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
   Node8* nS = reinterpret_cast<Node8*>(smem8);                   // [N8_CAP]
@@ -174,33 +191,159 @@ __global__ __launch_bounds__(256, 3) void gbdt_predict8_kernel(Pred8Args a) {
     for (int i = tid; i < (n1 - n0); i += 256) dst[i] = src[i];
     for (int i = tid; i < (l1 - l0); i += 256) lS[i] = a.leaves[l0 + i];
   }
-  const int64_t row = (int64_t)blockIdx.x * 64 + lane;
-  for (int i = tid; i < 64 * a.F; i += 256) {
-    const int r = i / a.F, f = i % a.F;
-    const int64_t gr = (int64_t)blockIdx.x * 64 + r;
-    xS[f * 64 + r] = (gr < a.n) ? a.X[gr * a.ldx + f] : 0.f;
+  // the workgroup keeps its tree chunk in LDS and walks candidate tile after candidate tile through it: the forest is
+  // read gridDim.x times in all instead of once per 64 candidates (1.4 GB of L2 traffic per 128k candidates before)
+  const int64_t n_tiles = (a.n + 63) / 64;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  const int64_t row = tile * 64 + lane;
+  __syncthreads();   // previous tile's walks and reduction are done with xS / red
+  {  // lane = candidate, wave w takes features w, w+4, ...: conflict-free writes of the transposed tile
+    const int64_t gr = tile * 64 + lane;
+    const float* xr = a.X + (gr < a.n ? gr : 0) * a.ldx;
+    for (int f = w; f < a.F; f += 4) {
+      float x = (gr < a.n) ? xr[f] : 0.f;
+      if (SIMPLE && x != x) x = 0.f;   // missing type None: a NaN feature decides like 0.0 at every node
+      xS[f * 64 + lane] = x;
+    }
   }
   __syncthreads();
   double acc = 0.0;
-  for (int t = t0 + w; t < t1; t += 4) {
-    const Node8* nodes = nS + (a.tree_node_off[t] - n0);
-    int node = a.tree_root[t];
-    while (node >= 0) {
-      const Node8 nd = nodes[node];
-      const float x = xS[nd.feat * 64 + lane];
-      const int m = (nd.flags >> 1) & 3;
-      const bool is_nan = x != x;
-      const float f = (is_nan && m != 2) ? 0.f : x;
-      const bool miss = (m == 1) ? (fabsf(f) <= a.zero_thr) : (m == 2 ? is_nan : false);
-      const bool left = miss ? (nd.flags & 1) : (f <= nd.thr);
-      node = left ? (int)nd.left : (int)nd.right;
+  // each lane walks IL trees at once: the walks are chains of two dependent LDS reads per level (node, then the
+  // feature it names), so independent chains are what fills the LDS pipe; leaves are added in tree order (as before)
+  constexpr int IL = 4;
+  for (int tb = t0 + w; tb < t1; tb += 4 * IL) {
+    const Node8* nodes[IL];
+    int node[IL];
+#pragma unroll
+    for (int j = 0; j < IL; ++j) {
+      const int t = tb + 4 * j;
+      const bool on = t < t1;
+      nodes[j] = nS + (a.tree_node_off[on ? t : tb] - n0);
+      node[j] = on ? a.tree_root[t] : -1;
     }
-    acc += lS[a.tree_leaf_off[t] - l0 + ~node];
+    // The walk is issue-bound (PMC: the SIMDs issue 86 % of the time), so the loop carries no per-lane branch: every
+    // lane takes `dmax` steps (the deepest of the IL trees); a lane that has reached a leaf (node < 0) keeps it.
+    int dmax = 0;
+#pragma unroll
+    for (int j = 0; j < IL; ++j) {
+      const int t = tb + 4 * j;
+      const int dj = t < t1 ? a.tree_depth[t] : 0;
+      dmax = dj > dmax ? dj : dmax;
+    }
+    for (int lvl = 0; lvl < dmax; ++lvl) {
+#pragma unroll
+      for (int j = 0; j < IL; ++j) {
+        const int cur = node[j];
+        const Node8 nd = nodes[j][cur > 0 ? cur : 0];
+        const float x = xS[nd.feat * 64 + lane];
+        bool left;
+        if (SIMPLE) {
+          left = x <= nd.thr;
+        } else {
+          const int m = (nd.flags >> 1) & 3;
+          const bool is_nan = x != x;
+          const float f = (is_nan && m != 2) ? 0.f : x;
+          const bool miss = (m == 1) ? (fabsf(f) <= a.zero_thr) : (m == 2 ? is_nan : false);
+          left = miss ? (nd.flags & 1) : (f <= nd.thr);
+        }
+        const int nxt = left ? (int)nd.left : (int)nd.right;
+        node[j] = cur >= 0 ? nxt : cur;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < IL; ++j) {
+      const int t = tb + 4 * j;
+      if (t < t1) acc += lS[a.tree_leaf_off[t] - l0 + ~node[j]];
+    }
   }
   red[w * 64 + lane] = acc;
   __syncthreads();
   if (w == 0 && row < a.n)
     a.part[(size_t)chunk * a.n + row] = ((red[lane] + red[64 + lane]) + red[128 + lane]) + red[192 + lane];
+  }
+}
+
+// ---- walk-ordered records: all-numerical forests without missing-value handling (missing type None everywhere) ----
+// The walk is instruction-issue bound (rocprofv3 PMC: the SIMDs issue 86 % of the cycles), so the node format is built
+// for the fewest instructions per level.  Per tree the nodes AND leaves are laid out breadth first as 8-byte records with
+// the two children of a node adjacent (left at a 16-byte boundary, right 8 bytes later):
+//   internal record  {f32 thr (rounded down), u16 byte offset of the LEFT child | (feature * 256) << 16}
+//   leaf record      {+inf,                   u16 own byte offset             | (4 * tree-local leaf index) << 16}
+// One level = one 8-byte LDS read, one 4-byte LDS read of the lane's feature, a compare and
+// `next = (word1 & 0xFFFF) | (x > thr ? 8 : 0)`; a leaf record points at itself, so every lane simply takes
+// depth(tree) steps (no per-lane branch, no exec masking) and then reads the leaf slot of where it stands.
+constexpr int R_CAP = 4096;  // records per chunk (32 KB of LDS)
+struct WalkArgs {
+  const uint2* rec; const double* leaves;
+  const int *tree_leaf_off, *chunk, *rec_chunk_off, *rec_root, *tree_depth;
+  const float* X; int64_t n; int F; int ldx;
+  double* part;
+};
+__global__ __launch_bounds__(256, 2) void gbdt_walk_kernel(WalkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smemw[];
+  unsigned char* rS = smemw;                                             // [R_CAP] records
+  double* lS = reinterpret_cast<double*>(rS + sizeof(uint2) * R_CAP);    // [L8_CAP]
+  double* red = lS + L8_CAP;                                             // [4][64]
+  unsigned char* xS = reinterpret_cast<unsigned char*>(red + 4 * 64);    // [F][64] floats, transposed
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int chunk = blockIdx.y;
+  const int t0 = a.chunk[chunk], t1 = a.chunk[chunk + 1];
+  const int r0 = a.rec_chunk_off[chunk], r1 = a.rec_chunk_off[chunk + 1];
+  const int l0 = a.tree_leaf_off[t0], l1 = a.tree_leaf_off[t1];
+  for (int i = tid; i < (r1 - r0); i += 256) reinterpret_cast<uint2*>(rS)[i] = a.rec[r0 + i];
+  for (int i = tid; i < (l1 - l0); i += 256) lS[i] = a.leaves[l0 + i];
+  const unsigned char* xL = xS + lane * 4;
+  const int64_t n_tiles = (a.n + 63) / 64;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t row = tile * 64 + lane;
+    __syncthreads();   // previous tile's walks and reduction are done with xS / red (first pass: records are staged)
+    {  // lane = candidate, wave w takes features w, w+4, ...: the transposed tile xS[f][candidate] is written without
+       // bank conflicts (lane-consecutive); the strided global reads of a candidate's row are absorbed by L1
+      const int64_t gr = tile * 64 + lane;
+      const float* xr = a.X + (gr < a.n ? gr : 0) * a.ldx;
+      for (int f = w; f < a.F; f += 4) {
+        float x = (gr < a.n) ? xr[f] : 0.f;
+        if (x != x) x = 0.f;         // missing type None: a NaN feature decides like 0.0 at every node
+        reinterpret_cast<float*>(xS)[f * 64 + lane] = x;
+      }
+    }
+    __syncthreads();
+    double acc = 0.0;
+    constexpr int IL = 4;            // trees walked at once by every lane (independent LDS chains)
+    for (int tb = t0 + w; tb < t1; tb += 4 * IL) {
+      unsigned cur[IL];
+      int dmax = 0;
+#pragma unroll
+      for (int j = 0; j < IL; ++j) {
+        const int t = tb + 4 * j;
+        const bool on = t < t1;
+        cur[j] = (unsigned)a.rec_root[on ? t : tb];
+        const int dj = on ? a.tree_depth[t] : 0;
+        dmax = dj > dmax ? dj : dmax;
+      }
+      for (int lvl = 0; lvl < dmax; ++lvl) {
+        bool moved = false;
+#pragma unroll
+        for (int j = 0; j < IL; ++j) {
+          const uint2 r = *reinterpret_cast<const uint2*>(rS + cur[j]);
+          const float x = *reinterpret_cast<const float*>(xL + (r.y >> 16));
+          const unsigned nxt = (r.y & 0xFFFFu) | (x > __uint_as_float(r.x) ? 8u : 0u);
+          moved |= nxt != cur[j];
+          cur[j] = nxt;
+        }
+        if (!__any(moved)) break;   // wave-uniform: every lane of the wave stands on a leaf in all IL trees
+      }
+#pragma unroll
+      for (int j = 0; j < IL; ++j) {   // leaves are added in tree order: bitwise reproducible
+        const int t = tb + 4 * j;
+        if (t < t1) acc += lS[a.tree_leaf_off[t] - l0 + (*reinterpret_cast<const unsigned*>(rS + cur[j] + 4) >> 18)];
+      }
+    }
+    red[w * 64 + lane] = acc;
+    __syncthreads();
+    if (w == 0 && row < a.n)
+      a.part[(size_t)chunk * a.n + row] = ((red[lane] + red[64 + lane]) + red[128 + lane]) + red[192 + lane];
+  }
 }
 
 __global__ void gbdt_reduce_kernel(const double* __restrict__ part, int n_chunks, int64_t n, double scale, double* out) {
@@ -256,6 +399,23 @@ static void build_compact(Forest* F, bool any_cat) {
     c.flags = (uint8_t)(((nd.dtype >> 1) & 1) | (((nd.dtype >> 2) & 3) << 1));
     F->nodes8[i] = c;
   }
+  F->simple8 = true;
+  for (const Node8& c : F->nodes8) if ((c.flags >> 1) & 3) F->simple8 = false;
+  F->depth8.assign(F->n_trees, 0);
+  for (int t = 0; t < F->n_trees; ++t) {   // longest path, iteratively (trees are small)
+    const Node* nd = F->nodes.data() + F->tree_node_off[t];
+    std::vector<std::pair<int, int>> stack;
+    if (F->tree_root[t] >= 0) stack.push_back({F->tree_root[t], 1});
+    int best = 0;
+    while (!stack.empty()) {
+      const std::pair<int, int> cur = stack.back();
+      stack.pop_back();
+      best = cur.second > best ? cur.second : best;
+      if (nd[cur.first].left >= 0) stack.push_back({nd[cur.first].left, cur.second + 1});
+      if (nd[cur.first].right >= 0) stack.push_back({nd[cur.first].right, cur.second + 1});
+    }
+    F->depth8[t] = best;
+  }
   F->zero_thr32 = f32_floor(1e-35);
   F->chunk8.clear();
   F->chunk8.push_back(0);
@@ -267,6 +427,47 @@ static void build_compact(Forest* F, bool any_cat) {
   }
   F->chunk8.push_back(F->n_trees);
   F->compact = true;
+  // ---- walk-ordered records (gbdt_walk_kernel)
+  F->bfs = false;
+  if (!F->simple8) return;
+  F->rec.clear(); F->rec_chunk_off.assign(1, 0); F->rec_root.assign(F->n_trees, 0);
+  float inf_f = INFINITY; uint32_t inf_bits; memcpy(&inf_bits, &inf_f, 4);
+  for (size_t c = 0; c + 1 < F->chunk8.size(); ++c) {
+    const int t0 = F->chunk8[c], t1 = F->chunk8[c + 1];
+    std::vector<uint2> cr;   // this chunk's records
+    for (int t = t0; t < t1; ++t) {
+      const Node8* nd = F->nodes8.data() + F->tree_node_off[t];
+      if (cr.size() % 2) cr.push_back(make_uint2(inf_bits, 0));   // roots and sibling pairs start at 16-byte boundaries
+      const size_t root = cr.size();
+      F->rec_root[t] = (int)(root * 8);
+      cr.push_back(make_uint2(0, 0));
+      cr.push_back(make_uint2(inf_bits, (unsigned)((root + 1) * 8)));   // pad: keeps the next pair 16-byte aligned
+      std::vector<std::pair<int, size_t>> queue;   // (node >= 0 or ~leaf, record index), breadth first
+      queue.push_back({F->tree_root[t], root});
+      for (size_t qi = 0; qi < queue.size(); ++qi) {
+        const int node = queue[qi].first;
+        const size_t at = queue[qi].second;
+        if (node < 0) {
+          // upper half = 4 * (tree-local leaf index): read as a feature offset by the walk, so it must stay a valid,
+          // 4-byte aligned offset into the feature tile (the value read there is irrelevant: thr = +inf)
+          const unsigned leaf4 = (unsigned)(~node) * 4u;
+          if (leaf4 > 0xFFFCu || (~node) > 127) return;
+          cr[at] = make_uint2(inf_bits, (unsigned)(at * 8) | (leaf4 << 16));
+        } else {
+          const size_t pair = cr.size();
+          cr.push_back(make_uint2(0, 0)); cr.push_back(make_uint2(0, 0));
+          uint32_t tb; memcpy(&tb, &nd[node].thr, 4);
+          cr[at] = make_uint2(tb, (unsigned)(pair * 8) | ((unsigned)nd[node].feat * 256u) << 16);
+          queue.push_back({(int)nd[node].left, pair});
+          queue.push_back({(int)nd[node].right, pair + 1});
+        }
+      }
+    }
+    if (cr.size() > (size_t)R_CAP) return;   // offsets must fit 16 bits and the chunk 32 KB of LDS
+    F->rec.insert(F->rec.end(), cr.begin(), cr.end());
+    F->rec_chunk_off.push_back((int)F->rec.size());
+  }
+  F->bfs = true;
 }
 
 int parse_model(const std::string& text, Forest* F) {
@@ -378,7 +579,7 @@ void destroy_forest(Forest* F) {
   if (!F) return;
   hipFree(F->d_nodes); hipFree(F->d_leaves); hipFree(F->d_tree_node_off); hipFree(F->d_tree_leaf_off); hipFree(F->d_tree_root);
   hipFree(F->d_chunk); hipFree(F->d_cat_b); hipFree(F->d_cat_w); hipFree(F->d_tree_cat_b_off); hipFree(F->d_tree_cat_w_off);
-  hipFree(F->d_part); hipFree(F->d_nodes8); hipFree(F->d_chunk8);
+  hipFree(F->d_part); hipFree(F->d_nodes8); hipFree(F->d_chunk8); hipFree(F->d_depth8); hipFree(F->d_rec); hipFree(F->d_rec_chunk_off); hipFree(F->d_rec_root);
   delete F;
 }
 
@@ -401,6 +602,8 @@ extern "C" int rihip_gbdt_create_from_text(const char* text, int64_t len, void**
     if (!rc && F->compact) {
       rc = upload(F->nodes8, &F->d_nodes8);
       if (!rc) rc = upload(F->chunk8, &F->d_chunk8);
+      if (!rc) rc = upload(F->depth8, &F->d_depth8);
+      if (!rc && F->bfs) { rc = upload(F->rec, &F->d_rec); if (!rc) rc = upload(F->rec_chunk_off, &F->d_rec_chunk_off); if (!rc) rc = upload(F->rec_root, &F->d_rec_root); }
     }
     if (!rc && !F->cat_boundaries.empty()) {
       rc = upload(F->cat_boundaries, &F->d_cat_b);
@@ -464,19 +667,48 @@ extern "C" int rihip_gbdt_predict(void* handle, const float* X, int64_t n, int l
     RIHIP_CHECK_HIP(hipMalloc((void**)&F->d_part, sizeof(double) * (size_t)n_chunks * n));
     F->part_elems = (int64_t)n_chunks * n;
   }
+  if (compact && F->bfs && F->d_rec) {
+    WalkArgs c;
+    c.rec = F->d_rec; c.leaves = F->d_leaves; c.tree_leaf_off = F->d_tree_leaf_off; c.chunk = F->d_chunk8;
+    c.rec_chunk_off = F->d_rec_chunk_off; c.rec_root = F->d_rec_root; c.tree_depth = F->d_depth8;
+    c.X = X; c.n = n; c.F = F->n_features; c.ldx = ldx; c.part = F->d_part;
+    const size_t lds = sizeof(uint2) * R_CAP + sizeof(double) * (L8_CAP + 4 * 64) + sizeof(float) * 64 * (size_t)F->n_features;
+    static bool granted_w = false;
+    if (!granted_w) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gbdt_walk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(sizeof(uint2) * R_CAP + sizeof(double) * (L8_CAP + 4 * 64) + sizeof(float) * 64 * 255));
+      granted_w = true;
+    }
+    const int64_t n_tiles8 = (n + 63) / 64;
+    int64_t per_chunk = (2 * RIHIP_NCU + n_chunks - 1) / n_chunks;     // 2 resident workgroups per CU over all chunks
+    if (per_chunk > n_tiles8) per_chunk = n_tiles8;
+    hipLaunchKernelGGL(gbdt_walk_kernel, dim3((unsigned)per_chunk, n_chunks), dim3(256), lds, st, c);
+    RIHIP_CHECK_LAUNCH();
+    const double scale_w = F->average_output ? 1.0 / (double)F->n_trees : 1.0;
+    hipLaunchKernelGGL(gbdt_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, F->d_part, n_chunks, n, scale_w, out);
+    RIHIP_CHECK_LAUNCH();
+    return RIHIP_OK;
+  }
   if (compact) {
     Pred8Args c;
     c.nodes = F->d_nodes8; c.leaves = F->d_leaves; c.tree_node_off = F->d_tree_node_off; c.tree_leaf_off = F->d_tree_leaf_off;
-    c.tree_root = F->d_tree_root; c.chunk = F->d_chunk8; c.X = X; c.n = n; c.F = F->n_features; c.ldx = ldx;
+    c.tree_root = F->d_tree_root; c.chunk = F->d_chunk8; c.tree_depth = F->d_depth8; c.X = X; c.n = n; c.F = F->n_features; c.ldx = ldx;
     c.zero_thr = F->zero_thr32; c.part = F->d_part;
     const size_t lds = sizeof(Node8) * N8_CAP + sizeof(double) * (L8_CAP + 4 * 64) + sizeof(float) * 64 * (size_t)F->n_features;
     static bool granted = false;
+    const int lds_max = (int)(sizeof(Node8) * N8_CAP + sizeof(double) * (L8_CAP + 4 * 64) + sizeof(float) * 64 * 255);
     if (!granted) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gbdt_predict8_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(Node8) * N8_CAP + sizeof(double) * (L8_CAP + 4 * 64) + sizeof(float) * 64 * 255));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gbdt_predict8_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gbdt_predict8_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
       granted = true;
     }
-    hipLaunchKernelGGL(gbdt_predict8_kernel, dim3((unsigned)((n + 63) / 64), n_chunks), dim3(256), lds, st, c);
+    const int64_t n_tiles8 = (n + 63) / 64;
+    int64_t per_chunk = (3 * RIHIP_NCU + n_chunks - 1) / n_chunks;     // 3 resident workgroups per CU over all chunks
+    if (per_chunk > n_tiles8) per_chunk = n_tiles8;
+    if (F->simple8) hipLaunchKernelGGL(gbdt_predict8_kernel<true>, dim3((unsigned)per_chunk, n_chunks), dim3(256), lds, st, c);
+    else hipLaunchKernelGGL(gbdt_predict8_kernel<false>, dim3((unsigned)per_chunk, n_chunks), dim3(256), lds, st, c);
     RIHIP_CHECK_LAUNCH();
     const double scale8 = F->average_output ? 1.0 / (double)F->n_trees : 1.0;
     hipLaunchKernelGGL(gbdt_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, F->d_part, n_chunks, n, scale8, out);

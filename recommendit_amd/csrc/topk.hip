@@ -33,6 +33,7 @@ namespace {
 
 constexpr int QB = 128;         // queries per workgroup (32 per wave)
 constexpr int SAMPLE = 16384;   // corpus rows scored for the threshold estimate
+constexpr int CSTRIDE = 32;     // IVF candidate counters: one 128-byte line per query (same-line atomics serialise in L2)
 
 __device__ __forceinline__ uint32_t f2ord(float f) {
   uint32_t u = __float_as_uint(f);
@@ -440,7 +441,8 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ X
 struct FinArgs {
   const uint64_t* cand;  // [nq, cap]
   int64_t cap;
-  const int* count;      // [nq]
+  const int* count;      // [nq * count_stride]
+  int count_stride;      // 0/1 = dense
   const int* qmap;       // optional: output slot -> query index inside cand/count (fallback), or null
   int64_t nq;
   int k;                 // requested k (<= K_MAX)
@@ -469,7 +471,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int64_t qi = blockIdx.x;
   const int64_t q = a.qmap ? a.qmap[qi] : qi;
-  const int cnt_raw = a.count[q];
+  const int cnt_raw = a.count[q * (a.count_stride > 1 ? a.count_stride : 1)];
   const int64_t n = cnt_raw < a.cap ? cnt_raw : a.cap;
   const uint64_t* keys = a.cand + (size_t)q * a.cap;
   const int64_t oslot = a.out_slot ? a.out_slot[qi] : qi;
@@ -620,9 +622,13 @@ struct LmArgs {
   const int* list_qoff;      // [nlist+1] first slot of each list in list_q
   const int* list_q;         // [nq*nprobe] query indices grouped by list
   const int* work_off;       // [nlist+1] first work item of each list
-  const int* plan;           // [0] = number of work items, [1] = tile splits per (list, query group)
+  const int* plan;           // [0] = number of work items, [1] = tiles per work item
   int nlist;
   int tile_step;             // visit every tile_step-th tile of a list (threshold sample), 1 = all
+  int nprobe;                // list_q holds pair indices q * nprobe + p
+  int count_stride;          // ints between two queries' candidate counters (32 = one 128-B line each: same-line
+                             // atomics serialise in L2)
+  int64_t dense_cap;         // > 0: threshold-sample pass, cand = [nq*nprobe, dense_cap] pre-zeroed key slots
 };
 
 // coarse scores cs[q, c] = <Q[q], C[c]> on exact-f32 MFMA (4 waves x 32 register-stationary queries, centroid tiles
@@ -729,22 +735,27 @@ __global__ __launch_bounds__(256) void ivf_plan_kernel(const int* __restrict__ l
     __syncthreads();
     return out;
   };
-  // pass 1: slots (queries per list) and the number of (list, 32-query group) pairs
+  // pass 1: slots (queries per list) and the total work = sum over (list, 32-query group) of the list's sampled tiles
   int m_sum = 0, g_sum = 0;
-  for (int c = c0; c < c1; ++c) { m_sum += list_cnt[c]; g_sum += (list_cnt[c] + 31) / 32; }
+  for (int c = c0; c < c1; ++c) {
+    const int64_t tiles = (list_poff[c + 1] - list_poff[c]) / TRS;
+    const int64_t n_seq = (tiles + tile_step - 1) / tile_step;
+    m_sum += list_cnt[c];
+    g_sum += ((list_cnt[c] + 31) / 32) * (int)n_seq;
+  }
   int q_off = block_excl(m_sum);
   const int m_total = s_total;
   (void)block_excl(g_sum);
-  const int n_lg = s_total;
-  int S = n_lg > 0 ? (target_items + n_lg - 1) / n_lg : 1;
-  if (S < 1) S = 1;
+  const int total_tiles = s_total;
+  // tiles per work item: every item gets about the same number of tiles, whatever the length of its list
+  int tpi = (total_tiles + target_items - 1) / (target_items > 0 ? target_items : 1);
+  if (tpi < 1) tpi = 1;
   // pass 2: work items
   int w_sum = 0;
   for (int c = c0; c < c1; ++c) {
     const int64_t tiles = (list_poff[c + 1] - list_poff[c]) / TRS;
     const int64_t n_seq = (tiles + tile_step - 1) / tile_step;
-    const int s_c = (int)(n_seq < S ? n_seq : S);
-    w_sum += ((list_cnt[c] + 31) / 32) * s_c;
+    w_sum += ((list_cnt[c] + 31) / 32) * (int)((n_seq + tpi - 1) / tpi);
   }
   int w_off = block_excl(w_sum);
   const int n_work = s_total;
@@ -753,24 +764,27 @@ __global__ __launch_bounds__(256) void ivf_plan_kernel(const int* __restrict__ l
     q_off += list_cnt[c];
     const int64_t tiles = (list_poff[c + 1] - list_poff[c]) / TRS;
     const int64_t n_seq = (tiles + tile_step - 1) / tile_step;
-    const int s_c = (int)(n_seq < S ? n_seq : S);
-    w_off += ((list_cnt[c] + 31) / 32) * s_c;
+    w_off += ((list_cnt[c] + 31) / 32) * (int)((n_seq + tpi - 1) / tpi);
   }
-  if (tid == 0) { list_qoff[nlist] = m_total; work_off[nlist] = n_work; plan[0] = n_work; plan[1] = S; }
+  if (tid == 0) { list_qoff[nlist] = m_total; work_off[nlist] = n_work; plan[0] = n_work; plan[1] = tpi; }
 }
 
 __global__ void ivf_scatter_kernel(const int* __restrict__ probe_list, int64_t n_pairs, int nprobe, int* list_cur, int* list_q) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_pairs) return;
   const int c = probe_list[i];
-  if (c >= 0) list_q[atomicAdd(&list_cur[c], 1)] = (int)(i / nprobe);
+  if (c >= 0) list_q[atomicAdd(&list_cur[c], 1)] = (int)i;   // the pair index: query = i / nprobe, probe rank = i % nprobe
 }
 
 template <int D>
 __global__ __launch_bounds__(256, 2) void ivf_scan_lm_kernel(LmArgs a) {
-  constexpr int KB = D / 8;
+  constexpr int KB = D / 8, LDX = D + 4;
+  constexpr int NL = (TRS * (D / 4)) / 64;  // 16-byte pieces per lane per tile (fully coalesced 1-KiB wave loads)
+  // wave-private staging tile: no workgroup barrier anywhere (a wave's LDS operations execute in order)
+  __shared__ __attribute__((aligned(16))) float Xs_all[4][TRS * LDX];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r31 = lane & 31, hh = lane >> 5;
+  float* Xs = Xs_all[w];
   const int wi = blockIdx.x * 4 + w;
   if (wi >= a.plan[0]) return;  // wave-uniform
   // which list: largest c with work_off[c] <= wi
@@ -785,38 +799,50 @@ __global__ __launch_bounds__(256, 2) void ivf_scan_lm_kernel(LmArgs a) {
   const int64_t tiles = (a.list_poff[c + 1] - p0) / TRS;
   const int tstep = a.tile_step > 1 ? a.tile_step : 1;
   const int64_t n_seq = (tiles + tstep - 1) / tstep;
-  const int S = a.plan[1];
-  const int s_c = (int)(n_seq < S ? n_seq : S);
+  const int tpi = a.plan[1];                              // tiles per work item
+  const int s_c = (int)((n_seq + tpi - 1) / tpi);
   const int grp = rem / s_c, split = rem % s_c;
   const int q0 = a.list_qoff[c], m = a.list_qoff[c + 1] - q0;
   const int slot = grp * 32 + r31;
   const bool q_ok = slot < m;
-  const int64_t q = a.list_q[q0 + (q_ok ? slot : grp * 32)];
+  const int pair = a.list_q[q0 + (q_ok ? slot : grp * 32)];   // pair = query * nprobe + probe rank
+  const int64_t q = pair / a.nprobe;
   const int len = a.list_len[c];
   f32x4 qf[KB];
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) qf[kb] = *reinterpret_cast<const f32x4*>(&a.Q[q * D + kb * 8 + 4 * hh]);
   const float thr = a.thr ? a.thr[q] : -INFINITY;
   uint64_t* my_cand = a.cand + (size_t)q * a.cap;
-  const int64_t per = (n_seq + s_c - 1) / s_c;
+  // dense mode (threshold sample): slot = (pair, sampled tile, row): no atomics, no row-id gather
+  uint64_t* my_dense = a.dense_cap > 0 ? a.cand + (size_t)pair * a.dense_cap : nullptr;
+  const int64_t per = tpi;
   const int64_t i0 = (int64_t)split * per;
   const int64_t i1 = (i0 + per < n_seq) ? i0 + per : n_seq;
   if (i0 >= i1) return;
 
-  f32x4 xa[KB], xb[KB];
-  auto load_tile = [&](f32x4* dst, int64_t i) {
-    const float* row = a.X + (size_t)(p0 + i * tstep * TRS + r31) * D + 4 * hh;
+  f32x4 stage[NL];
+  auto load_tile = [&](int64_t i) {  // rows of the tile are contiguous: lane l takes bytes [1024 j + 16 l, +16)
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.X + (size_t)(p0 + i * tstep * TRS) * D) + lane;
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) dst[kb] = *reinterpret_cast<const f32x4*>(row + kb * 8);
+    for (int j = 0; j < NL; ++j) stage[j] = src[j * 64];
   };
-  auto chain = [&](const f32x4* x) -> f32x16 {
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      const int idx = j * 64 + lane;                 // 16-byte piece of the tile
+      const int r = idx / (D / 4), c4 = idx % (D / 4);
+      *reinterpret_cast<f32x4*>(&Xs[r * LDX + c4 * 4]) = stage[j];
+    }
+  };
+  auto chain = [&]() -> f32x16 {
     f32x16 acc = zero16();
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
-      acc = mfma32(x[kb].x, qf[kb].x, acc);
-      acc = mfma32(x[kb].y, qf[kb].y, acc);
-      acc = mfma32(x[kb].z, qf[kb].z, acc);
-      acc = mfma32(x[kb].w, qf[kb].w, acc);
+      const f32x4 av = *reinterpret_cast<const f32x4*>(&Xs[r31 * LDX + kb * 8 + 4 * hh]);
+      acc = mfma32(av.x, qf[kb].x, acc);
+      acc = mfma32(av.y, qf[kb].y, acc);
+      acc = mfma32(av.z, qf[kb].z, acc);
+      acc = mfma32(av.w, qf[kb].w, acc);
     }
     return acc;
   };
@@ -825,12 +851,21 @@ __global__ __launch_bounds__(256, 2) void ivf_scan_lm_kernel(LmArgs a) {
     const int64_t t_row0 = i * tstep * TRS;              // first row of the tile inside the list
     const int64_t left = (int64_t)len - t_row0;           // list padding rows are never candidates
     const int n_ok = left >= TRS ? TRS : (left > 0 ? (int)left : 0);
+    if (my_dense) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = acc_row(r, lane);
+        const int64_t sl = i * TRS + rr;
+        if (sl < a.dense_cap) my_dense[sl] = rr < n_ok ? make_key(acc[r], 0u) : 0ull;
+      }
+      return;
+    }
     unsigned hits = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r)
       if (acc_row(r, lane) < n_ok && acc[r] >= thr) hits |= (1u << r);
     if (hits) {
-      int pos = atomicAdd(&a.count[q], __popc(hits));
+      int pos = atomicAdd(&a.count[q * a.count_stride], __popc(hits));
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         if (hits & (1u << r)) {
@@ -841,15 +876,15 @@ __global__ __launch_bounds__(256, 2) void ivf_scan_lm_kernel(LmArgs a) {
       }
     }
   };
-  load_tile(xa, i0);
+  load_tile(i0);
+  store_tile();
 #pragma unroll 1
-  for (int64_t i = i0; i < i1; i += 2) {
-    if (i + 1 < i1) load_tile(xb, i + 1);
-    emit(chain(xa), i);
-    if (i + 1 < i1) {
-      if (i + 2 < i1) load_tile(xa, i + 2);
-      emit(chain(xb), i + 1);
-    }
+  for (int64_t i = i0; i < i1; ++i) {
+    const bool more = i + 1 < i1;
+    if (more) load_tile(i + 1);          // in flight during this tile's MFMA chain
+    const f32x16 acc = chain();
+    if (more) store_tile();              // after the chain's LDS reads (same wave: in order)
+    emit(acc, i);
   }
 }
 
@@ -912,7 +947,7 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
   const int64_t n_tiles = (Nphys + TRS - 1) / TRS;
   const unsigned nqb = (unsigned)((nq + 255) / 256);
   const unsigned qgrid = (unsigned)((nq + QB - 1) / QB);
-  RCCHK(h->count.reserve(nq));
+  RCCHK(h->count.reserve(nq * CSTRIDE));
   RCCHK(h->fail_flags.reserve(nq));
   RCCHK(h->fail_list.reserve(nq));
   RCCHK(h->thr.reserve(nq));
@@ -937,16 +972,18 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
     const int nprobe = h->nprobe < nlist ? h->nprobe : nlist;
     RIHIP_REQUIRE(nlist <= NLIST_MAX, RIHIP_ERR_SHAPE, "ip_index: nlist=%d > %d unsupported", nlist, NLIST_MAX);
     // one IVF pass over `n` queries: plan (tile split for this sampling step) -> list-major scan
-    auto ivf_scan = [&](const float* Qp, int64_t n, const float* thr, uint64_t* cand, int64_t cap, int tile_step) -> int {
+    auto ivf_scan = [&](const float* Qp, int64_t n, const float* thr, uint64_t* cand, int64_t cap, int tile_step,
+                        int64_t dense_cap) -> int {
       const int target = 16 * RIHIP_NCU;  // wave work items aimed at: 2 waves per SIMD on every CU, twice over
       hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(256), 0, st, h->list_cnt.p, h->list_poff, nlist, tile_step, target,
-                         h->list_qoff.p, h->list_cur.p, h->work_off.p, h->plan.p, h->count.p, n);
+                         h->list_qoff.p, h->list_cur.p, h->work_off.p, h->plan.p, h->count.p, n * CSTRIDE);
       LmArgs x;
       memset(&x, 0, sizeof(x));
       x.X = h->X; x.Q = Qp; x.thr = thr; x.cand = cand; x.cap = cap; x.count = h->count.p; x.row_ids = h->row_ids;
       x.list_poff = h->list_poff; x.list_len = h->list_len_dev; x.list_qoff = h->list_qoff.p; x.list_q = h->list_q.p;
-      x.work_off = h->work_off.p; x.plan = h->plan.p; x.nlist = nlist; x.tile_step = tile_step;
-      // n_work <= target + #(list, query group) pairs <= target + nlist + n*nprobe/32
+      x.work_off = h->work_off.p; x.plan = h->plan.p; x.nlist = nlist; x.tile_step = tile_step; x.nprobe = nprobe;
+      x.dense_cap = dense_cap; x.count_stride = CSTRIDE;
+      // n_work <= sum over (list, group) of (tiles/tpi + 1) <= target + #(list, query group) pairs
       const int64_t bound = (int64_t)target + nlist + (n * nprobe + 31) / 32 + 4;
       const dim3 grid((unsigned)((bound + 3) / 4));
       if (d == 32) hipLaunchKernelGGL((ivf_scan_lm_kernel<32>), grid, dim3(256), 0, st, x);
@@ -979,11 +1016,11 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
     auto ivf_full = [&](const float* Qp, int64_t n, const int* out_slot) -> int {
       RCCHK(h->fcand.reserve(n * cap_full));
       RCCHK(ivf_prepare(Qp, n));
-      RCCHK(ivf_scan(Qp, n, nullptr, h->fcand.p, cap_full, 1));
+      RCCHK(ivf_scan(Qp, n, nullptr, h->fcand.p, cap_full, 1, 0));
       FinArgs f2;
       memset(&f2, 0, sizeof(f2));
       f2.nq = n; f2.k = k; f2.count = h->count.p; f2.out_scores = out_s; f2.out_rows = out_r; f2.cand = h->fcand.p;
-      f2.cap = cap_full; f2.mode = 0; f2.out_slot = out_slot;
+      f2.cap = cap_full; f2.mode = 0; f2.out_slot = out_slot; f2.count_stride = CSTRIDE;
       RCCHK(launch_finalize(f2, (unsigned)n, st));
       return check_launch("finalize");
     };
@@ -995,16 +1032,22 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
     int64_t cap = 4096;
     while ((double)cap < 2.5 * rank * SS) cap <<= 1;
     if (cap > cap_full) cap = cap_full;
-    const int64_t cap_s = cap_full / SS + 2 * TR * h->nprobe + 64;
+    // pass A: every SS-th tile of each probed list, all of its scores kept in dense per-(query, probe) slots
+    int64_t max_tiles = 0;
+    for (int c = 0; c < nlist; ++c) max_tiles = std::max<int64_t>(max_tiles, (h->list_len[c] + TR - 1) / TR * (TR / TRS));
+    const int64_t cap_l = (max_tiles + SS - 1) / SS * TRS;             // sampled rows of the longest list
+    const int64_t cap_s = cap_l * nprobe;
     RCCHK(h->scand.reserve(nq * cap_s));
     RCCHK(h->cand.reserve(nq * cap));
     RCCHK(ivf_prepare(Q, nq));
-    RCCHK(ivf_scan(Q, nq, nullptr, h->scand.p, cap_s, SS));                      // pass A: sampled tiles, no filter
+    HIPCHK(hipMemsetAsync(h->scand.p, 0, sizeof(uint64_t) * (size_t)(nq * cap_s), st));   // key 0 = below every score
+    RCCHK(ivf_scan(Q, nq, nullptr, h->scand.p, cap_s, SS, cap_l));
+    hipLaunchKernelGGL(fill_int_kernel, dim3(nqb), dim3(256), 0, st, h->count.p, nq, (int)cap_s);
     fa.cand = h->scand.p; fa.cap = cap_s; fa.mode = 1; fa.rank = rank; fa.thr_out = h->thr.p;
     RCCHK(launch_finalize(fa, (unsigned)nq, st));
-    RCCHK(ivf_scan(Q, nq, h->thr.p, h->cand.p, cap, 1));                         // pass B: all probed tiles, filtered
+    RCCHK(ivf_scan(Q, nq, h->thr.p, h->cand.p, cap, 1, 0));                         // pass B: all probed tiles, filtered
     fa.cand = h->cand.p; fa.cap = cap; fa.mode = 0; fa.thr_out = nullptr; fa.fail_flags = h->fail_flags.p;
-    fa.ivf_thr = h->thr.p;
+    fa.ivf_thr = h->thr.p; fa.count_stride = CSTRIDE;
     RCCHK(launch_finalize(fa, (unsigned)nq, st));
     hipLaunchKernelGGL(fill_int_kernel, dim3(1), dim3(64), 0, st, h->n_fail.p, 1, 0);
     hipLaunchKernelGGL(collect_fail_kernel, dim3(nqb), dim3(256), 0, st, h->fail_flags.p, nq, h->fail_list.p, h->n_fail.p);
