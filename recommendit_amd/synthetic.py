@@ -18,13 +18,15 @@ N_GENRES = len(GENRES)
 
 
 def ml1m_like(n_users: int = 6040, n_item_ids: int = 3952, n_catalog: int = 3883, n_ratings: int = 1_000_209,
-              rank: int = 8, seed: int = 0, affinity: float = 2.0) -> Tuple[pd.DataFrame, pd.DataFrame, np.ndarray]:
+              rank: int = 8, seed: int = 0, affinity: float = 0.8, shuffle_time: bool = False) -> Tuple[pd.DataFrame, pd.DataFrame, np.ndarray]:
     """Returns (ratings_df[user_id,item_id,rating,timestamp], movies_df[item_id,title,genres], genre_matrix
     [n_item_ids+1,18] f32).  Deterministic for a given seed.
-    `affinity` weights the latent user-item affinity against popularity when a user picks what to rate; each user's
-    ratings are time-stamped in a random order, so the "last 10 % by timestamp" test split of the reference's
-    run_evaluate is an unbiased sample of the user's items (round 1 stamped them in draw order, which put the
-    LEAST preferred items into the test split and made NDCG@10 ~0.02)."""
+    `affinity` weights the latent user-item affinity against popularity when a user picks what to rate.  Ratings are
+    time-stamped in draw order by default (weighted sampling without replacement draws a user's strongest items
+    first, so the "last 10 % by timestamp" test split of the reference's run_evaluate holds the user's weakest picks
+    and NDCG@10 stays ~0.02 -- the G9 fixture was generated on exactly this set); `shuffle_time=True` stamps them in
+    a random order instead.  Both were tried for G9: with the reference's 10 epochs at lr 1e-3 the model mostly learns
+    popularity either way (NDCG@10 0.016-0.02), so the per-epoch loss curve remains the tight parity check."""
     rng = np.random.RandomState(seed)
     catalog = np.sort(rng.choice(np.arange(1, n_item_ids + 1), size=n_catalog, replace=False))
     zu = rng.randn(n_users + 1, rank).astype(np.float32)
@@ -43,7 +45,9 @@ def ml1m_like(n_users: int = 6040, n_item_ids: int = 3952, n_catalog: int = 3883
         aff = zi[catalog] @ zu[u]
         w = pop * np.exp(affinity * (aff - aff.max()))
         w /= w.sum()
-        it = rng.permutation(rng.choice(catalog, size=c, replace=False, p=w))
+        it = rng.choice(catalog, size=c, replace=False, p=w)
+        if shuffle_time:
+            it = rng.permutation(it)
         users.append(np.full(c, u, dtype=np.int64))
         items.append(it.astype(np.int64))
     users = np.concatenate(users)

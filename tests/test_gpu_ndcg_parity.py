@@ -3,12 +3,13 @@ src/training/train_embeddings.py, run on CPU in the build container by oracle/ma
 trainer are both trained on the same seeded ML-1M-shaped synthetic set with the reference's settings (d=64,
 B=1024, lr=1e-3, 10 epochs, dropout 0.1, one sampled negative per positive, dense Adam + L2 + clip) and scored
 with the reference's run_evaluate protocol in its retrieval-only form.  Both procedures are stochastic
-(different RNG streams for shuffling, negatives and dropout), so the comparison is between seed means:
-* the reference's own protocol (first 200 test users): |mean NDCG@10 - reference mean| <= max(0.002, spread of the
-  reference's seeds) -- 200 users make single runs noisy (seed spread ~0.009);
-* the same metric over ALL test users (no user-sampling noise; what remains is the seed-to-seed variance of the
-  trained model, std ~0.003 for the reference itself): |mean - reference mean| <= max(0.002, 2 standard errors of the
-  difference of the two 6-seed means); 0.002 is the tolerance BASELINE.json's north_star states."""
+(different RNG streams for shuffling, negatives and dropout), so the comparison is between 6-seed means, and the
+tolerance is the one BASELINE.json's north_star states, asserted outright: |mean NDCG@10 - reference mean| <= 0.002
+* under the reference's own protocol (first 200 test users), and
+* over ALL test users (same metric, no user-sampling noise).
+Measured in round 1: 0.0002 and 0.0006.  The synthetic set makes NDCG@10 small (~0.02: with 10 epochs at lr 1e-3 the
+model mostly learns popularity), so the per-epoch training-loss curve (every epoch mean within 4e-3 of the
+reference's; measured <= 3e-4) is the tight check."""
 import json
 
 import numpy as np
@@ -41,8 +42,8 @@ def test_ndcg_and_loss_curve_match_reference_band(golden_dir, tmp_path):
     print("reference loss:", ref_loss.mean(0).round(4), "HIP loss:", got_loss.mean(0).round(4))
     # training loss curve: every epoch mean within 0.004 of the reference's epoch mean
     np.testing.assert_allclose(got_loss.mean(0), ref_loss.mean(0), atol=4e-3, rtol=0)
-    band = max(0.002, float(ref_ndcg.max() - ref_ndcg.min()))
-    assert abs(got_ndcg.mean() - ref_ndcg.mean()) <= band, (got_ndcg, ref_ndcg, band)
-    se = float(np.sqrt(ref_all.var(ddof=1) / len(ref_all) + got_all.var(ddof=1) / len(got_all)))
-    print("all users: |delta mean| =", abs(got_all.mean() - ref_all.mean()), "2 SE =", 2 * se)
-    assert abs(got_all.mean() - ref_all.mean()) <= max(0.002, 2.0 * se), (got_all, ref_all, se)
+    np.testing.assert_allclose(got_loss.mean(0), ref_loss.mean(0), atol=1e-3, rtol=0)   # measured: <= 3e-4
+    print("200-user protocol: |delta mean| =", abs(got_ndcg.mean() - ref_ndcg.mean()))
+    print("all users:         |delta mean| =", abs(got_all.mean() - ref_all.mean()))
+    assert abs(got_ndcg.mean() - ref_ndcg.mean()) <= 0.002, (got_ndcg, ref_ndcg)
+    assert abs(got_all.mean() - ref_all.mean()) <= 0.002, (got_all, ref_all)
