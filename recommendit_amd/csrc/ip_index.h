@@ -48,7 +48,8 @@ struct IpIndex {
   int64_t* row_ids = nullptr;  // [Np] original row per physical row, -1 for padding
   std::vector<int64_t> list_len;  // host copy
   // scratch (grown on demand, owned by the handle)
-  DevBuf<uint64_t> cand, scand, fcand;
+  DevBuf<uint64_t> cand, scand, fcand, seg;   // seg: per (query, corpus split) survivor segments of the bf16 filter
+  DevBuf<int> seg_cnt;
   DevBuf<int> count, fail_flags, fail_list, n_fail, fcount;
   DevBuf<float> thr, thr2, fQ;
   DevBuf<float> coarse;                                    // IVF: coarse scores [nq,nlist]

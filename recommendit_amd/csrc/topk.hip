@@ -61,6 +61,12 @@ struct ScanArgs {
   int nsplit;            // splits of the tile sequence (gridDim.y)
   int dense;             // 1: slot = virtual row (no atomics, count preset); 0: atomic append
   int qgrid;                  // bf16 filter: number of query blocks (1-D XCD-aware launch)
+  // bf16 filter: every (query, corpus split) pair has ONE writer (a wave), so its survivors go to a private segment
+  // with the fill count kept in LDS -- no global atomic in the scan (returning global atomics cost 0.64 of 1.8 ms)
+  uint64_t* seg;              // [nq, nsplit, seg_cap] keys
+  int* seg_cnt;               // [nq, nsplit] survivors found (may exceed seg_cap: the query is then re-done exactly)
+  int seg_cap;
+  int cs;                     // ints between two queries' candidate counters (0/1 = dense; CSTRIDE = a 128-B line each)
 };
 
 
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void scan_kernel(ScanArgs a) {
     for (int r = 0; r < 16; ++r)
       if (acc_row(r, lane) < n_ok && acc[r] >= thr) hits |= (1u << r);
     if (hits) {
-      int pos = atomicAdd(&a.count[q], __popc(hits));
+      int pos = atomicAdd(&a.count[q * (a.cs > 1 ? a.cs : 1)], __popc(hits));
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         if (hits & (1u << r)) {
@@ -213,6 +219,7 @@ constexpr int QBB = 256;  // queries per workgroup of the bf16 filter (64 per wa
 
 constexpr int TRB = 64;     // corpus rows per pipeline stage of the bf16 filter (two 32-row MFMA sub-tiles)
 constexpr int QCOLS = 192;  // survivor queue: 16-score accumulator columns per workgroup (LDS)
+constexpr int SAMPLE_T = 8;  // threshold sample: scores kept per stream (query, corpus split, row half)
 
 __device__ __forceinline__ float max3_raw(float a, float b, float c) {  // no NaN-canonicalising pre-ops
   float m;
@@ -236,18 +243,29 @@ __device__ __noinline__ void scan_slow_append(const float* col16, float th, int6
 
 // DENSE=false: survivors (score >= thr[q]) are queued in LDS and flushed to the per-query candidate lists now and then,
 // so the hot loop contains no global store/atomic (those make hipcc drain the in-flight prefetch with vmcnt(0)).
-// DENSE=true: every score is stored at slot = virtual row (threshold-sample pass).
-template <int D, bool DENSE>
+// MODE 1 (dense): every score is stored at slot = virtual row (threshold-sample pass for large k).
+// MODE 2 (top-T sample): every lane keeps the SAMPLE_T best scores of its stream (query, split, half of the rows) in
+// registers and writes only those: the r-th largest of the union is a LOWER bound of the sample's r-th largest (a
+// subset can only lose large scores), i.e. a safe threshold, and the sample pass writes 100x less.
+template <int D, int MODE>
 __global__ __launch_bounds__(256, 3) void scan_bf16_kernel(ScanArgs a) {
+  constexpr bool DENSE = MODE != 0;
   constexpr int LDB = D + 8, KB = D / 16;
   constexpr int NV = (TRB * (D / 8) + 255) / 256;  // 16-byte pieces staged per thread per stage
   __shared__ __attribute__((aligned(16))) __bf16 Xs[2][TRB * LDB];
-  // A survivor is rare per lane but not per 64-lane wave, so the hot path must stay tiny: a lane whose 16-score
-  // column holds a candidate just dumps the whole column (4 x ds_write_b128 + header) into this queue; thresholding
-  // per element and the global appends happen in flush(), amortised over ~128 columns.
+  // A survivor is rare per lane but not per 64-lane wave (a wave meets one in ~90 % of its 16-score columns at k = 500),
+  // so the hot path must neither wait nor synchronise: a lane whose column holds a candidate dumps the whole column
+  // (4 x ds_write_b128 + header) into its WAVE's private queue at a slot computed from a ballot (no LDS atomic, no
+  // returning operation: with a workgroup-wide atomic counter this path cost more than the MFMA work -- 0.9 of
+  // 1.85 ms, measured by switching it off); thresholding per element and the global appends happen in flush().
+  constexpr int WQ = QCOLS / 4;   // columns per wave queue
   __shared__ __attribute__((aligned(16))) float qsc[DENSE ? 1 : QCOLS][16];
   __shared__ unsigned qhdr[DENSE ? 1 : QCOLS][2];
-  __shared__ unsigned q_cnt;
+  __shared__ float thrS[DENSE ? 1 : QBB];   // thresholds of the block's queries (read by the flush)
+  __shared__ int qcntS[DENSE ? 1 : QBB];    // survivors of each query in this corpus split (one writer wave each)
+  __shared__ unsigned wcnt[2][4];           // queue lengths published at the stage barrier, double-buffered by parity
+  int wpar = 0;
+  unsigned wq_cnt = 0;            // wave-uniform: columns in this wave's queue
   const __bf16* Xb = reinterpret_cast<const __bf16*>(a.Xb);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r31 = lane & 31, hh = lane >> 5;
@@ -281,34 +299,57 @@ __global__ __launch_bounds__(256, 3) void scan_bf16_kernel(ScanArgs a) {
   const int64_t i0 = (int64_t)by * per;
   const int64_t i1 = (i0 + per < n_seq) ? i0 + per : n_seq;
   if (i0 >= i1) return;
-  if (tid == 0) q_cnt = 0;
+  if (!DENSE) {   // visible to the flush after the first stage barrier
+    if (hh == 0) { thrS[ql0] = ok0 ? th0 : INFINITY; thrS[ql1] = ok1 ? th1 : INFINITY; qcntS[ql0] = 0; qcntS[ql1] = 0; }
+  }
 
-  bf16x8_t stage[NV];
-  auto load_tile = [&](int64_t tile) {
+  // staging: every thread owns the same (row-in-16, 16-byte column) slot of each 16-row slab of a stage, so a full
+  // tile of the contiguous corpus is NV loads off ONE per-thread pointer with compile-time offsets
+  bf16x8_t stA[NV], stB[NV];
+  const int sr0 = tid / (D / 8), sc8 = tid % (D / 8);
+  constexpr int SROWS = 256 / (D / 8);   // rows covered by one load instruction of the workgroup
+  const __bf16* my_src = Xb + (size_t)sr0 * D + sc8 * 8;
+  auto load_tile = [&](bf16x8_t* stage, int64_t tile) {
     const int64_t v_base = tile * TRB;
+    if (a.row_stride == 1 && v_base + TRB <= a.n_virtual) {   // workgroup-uniform fast path
+      const __bf16* src = my_src + (size_t)v_base * D;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) stage[i] = *reinterpret_cast<const bf16x8_t*>(src + (size_t)i * SROWS * D);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int idx = tid + i * 256;
-      const int r = idx / (D / 8), c8 = idx % (D / 8);
-      const int64_t v = v_base + r;
+      const int64_t v = v_base + sr0 + i * SROWS;
       bf16x8_t val;
 #pragma unroll
       for (int j = 0; j < 8; ++j) val[j] = (__bf16)0.f;
-      if (idx < TRB * (D / 8) && v < a.n_virtual)
-        val = *reinterpret_cast<const bf16x8_t*>(Xb + (size_t)(v * a.row_stride) * D + c8 * 8);
+      if (sr0 + i * SROWS < TRB && v < a.n_virtual)
+        val = *reinterpret_cast<const bf16x8_t*>(Xb + (size_t)(v * a.row_stride) * D + sc8 * 8);
       stage[i] = val;
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](const bf16x8_t* stage, int buf) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int idx = tid + i * 256;
-      const int r = idx / (D / 8), c8 = idx % (D / 8);
-      if (idx < TRB * (D / 8)) *reinterpret_cast<bf16x8_t*>(&Xs[buf][r * LDB + c8 * 8]) = stage[i];
-    }
+    for (int i = 0; i < NV; ++i)
+      if (sr0 + i * SROWS < TRB) *reinterpret_cast<bf16x8_t*>(&Xs[buf][(sr0 + i * SROWS) * LDB + sc8 * 8]) = stage[i];
   };
+  float top0[SAMPLE_T], top1[SAMPLE_T];
+#pragma unroll
+  for (int i = 0; i < SAMPLE_T; ++i) { top0[i] = -INFINITY; top1[i] = -INFINITY; }
   auto emit = [&](const f32x16& acc, int64_t v_base, int ql, bool ok, float th, int64_t qrow) {
-    if (!ok) return;
+    if (MODE != 0 && !ok) return;   // MODE 0: every lane takes part in the ballot below (wq_cnt must stay wave-uniform)
+    if (MODE == 2) {
+      float* top = (ql == ql0) ? top0 : top1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float sc = (v_base + acc_row(r, lane) < a.n_virtual) ? acc[r] : -INFINITY;
+        // insert into the descending list: t_i' = med3(t_{i-1}, s, t_i) (in place, from the tail)
+#pragma unroll
+        for (int i = SAMPLE_T - 1; i > 0; --i) top[i] = __builtin_amdgcn_fmed3f(top[i - 1], sc, top[i]);
+        top[0] = fmaxf(top[0], sc);
+      }
+      return;
+    }
     if (DENSE) {
       uint64_t* cnd = a.cand + (size_t)qrow * a.cap;
 #pragma unroll
@@ -318,47 +359,92 @@ __global__ __launch_bounds__(256, 3) void scan_bf16_kernel(ScanArgs a) {
       }
       return;
     }
-    float mx = max3_raw(acc[0], acc[1], acc[2]);
-    mx = max3_raw(mx, acc[3], acc[4]);
-    mx = max3_raw(mx, acc[5], acc[6]);
-    mx = max3_raw(mx, acc[7], acc[8]);
-    mx = max3_raw(mx, acc[9], acc[10]);
-    mx = max3_raw(mx, acc[11], acc[12]);
-    mx = max3_raw(mx, acc[13], acc[14]);
-    mx = fmaxf(mx, acc[15]);
-    if (!(mx >= th)) return;  // no survivor in this 16-score column (the common case)
-    const unsigned pos = atomicAdd(&q_cnt, 1u);  // LDS
-    if (pos < (unsigned)QCOLS) {
-      f32x4* dst = reinterpret_cast<f32x4*>(qsc[pos]);
+    // The v_max3 chain is inline asm, which the compiler's MFMA->VALU hazard recognizer does not see: the chain must
+    // not be the first reader of the accumulator (it read stale registers when it directly followed the MFMAs and
+    // lost survivors).  The compiler-visible fmaxf below reads the accumulator first (hipcc pads it with the required
+    // wait states) and seeds the chain, so every asm read is ordered behind it.
+    float mx = fmaxf(acc[14], acc[15]);
+    mx = max3_raw(mx, acc[0], acc[1]);
+    mx = max3_raw(mx, acc[2], acc[3]);
+    mx = max3_raw(mx, acc[4], acc[5]);
+    mx = max3_raw(mx, acc[6], acc[7]);
+    mx = max3_raw(mx, acc[8], acc[9]);
+    mx = max3_raw(mx, acc[10], acc[11]);
+    mx = max3_raw(mx, acc[12], acc[13]);
+    const bool has = ok && mx >= th;
+    const unsigned long long bal = __ballot(has);
+    if (bal == 0ull) return;             // wave-uniform: no survivor in the wave's 64 columns
+    const unsigned pos = wq_cnt + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+    wq_cnt += (unsigned)__popcll(bal);
+    if (!has) return;
+    if (pos < (unsigned)WQ) {
+      const unsigned slot = (unsigned)w * WQ + pos;
+      f32x4* dst = reinterpret_cast<f32x4*>(qsc[slot]);
       dst[0] = f32x4{acc[0], acc[1], acc[2], acc[3]};
       dst[1] = f32x4{acc[4], acc[5], acc[6], acc[7]};
       dst[2] = f32x4{acc[8], acc[9], acc[10], acc[11]};
       dst[3] = f32x4{acc[12], acc[13], acc[14], acc[15]};
-      qhdr[pos][0] = (unsigned)ql | ((unsigned)hh << 16);
-      qhdr[pos][1] = (unsigned)v_base;
+      qhdr[slot][0] = (unsigned)ql | ((unsigned)hh << 16);
+      qhdr[slot][1] = (unsigned)v_base;
     } else {  // queue full: rare slow path, still exact
       float col[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) col[r] = acc[r];
-      scan_slow_append(col, th, v_base, hh, a.n_virtual, &a.count[qrow], a.cand + (size_t)qrow * a.cap, a.cap);
+      scan_slow_append(col, th, v_base, hh, a.n_virtual, &qcntS[ql], a.seg + ((size_t)qrow * a.nsplit + by) * a.seg_cap, a.seg_cap);
     }
   };
-  auto flush = [&]() {  // all threads: queue columns -> per-query candidate lists (16 threads per column)
-    const unsigned n = q_cnt < (unsigned)QCOLS ? q_cnt : (unsigned)QCOLS;
-    for (unsigned e = tid; e < n * 16; e += 256) {
-      const unsigned c = e >> 4, r = e & 15;
-      const unsigned h0 = qhdr[c][0];
-      const int64_t qg = qb0 + (h0 & 0xFFFFu);
-      const int64_t v = (int64_t)qhdr[c][1] + (r & 3) + 8 * (r >> 2) + 4 * (h0 >> 16);
-      const float sc = qsc[c][r];
-      if (v < a.n_virtual && sc >= a.thr[qg]) {
-        const int pos = atomicAdd(&a.count[qg], 1);
-        if (pos < a.cap) a.cand[(size_t)qg * a.cap + pos] = make_key(sc, (uint32_t)v);
+  // The wave empties its OWN queue (no barrier, no other wave involved): columns -> per-query candidate lists, 16 lanes
+  // per column, 4 columns per step, 4 steps batched so that their LDS reads, returning atomics (one per column, not
+  // per survivor) and stores are in flight together (done one step at a time the flush was latency-bound and cost as
+  // much as the MFMA work).
+  auto wave_flush = [&]() {
+    const unsigned n = wq_cnt < (unsigned)WQ ? wq_cnt : (unsigned)WQ;   // columns beyond WQ went the slow path
+    const int l15 = lane & 15, g4 = lane >> 4;
+    for (unsigned c0 = 0; c0 < n; c0 += 16) {
+      float sc[4]; int64_t qg[4], v[4]; bool hit[4]; unsigned grp[4]; int base[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned col = c0 + 4 * j + g4;
+        const bool in = col < n;
+        const unsigned c = (unsigned)w * WQ + (in ? col : 0);
+        const unsigned h0 = qhdr[c][0];
+        const unsigned ql = h0 & 0xFFFFu;
+        qg[j] = qb0 + ql;
+        v[j] = (int64_t)qhdr[c][1] + (l15 & 3) + 8 * (l15 >> 2) + 4 * (h0 >> 16);
+        sc[j] = qsc[c][l15];
+        hit[j] = in && v[j] < a.n_virtual && sc[j] >= thrS[ql];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned long long bal = __ballot(hit[j]);
+        grp[j] = (unsigned)(bal >> (16 * g4)) & 0xFFFFu;
+        base[j] = 0;
+        if (grp[j] && l15 == __ffs(grp[j]) - 1) base[j] = atomicAdd(&qcntS[qg[j] - qb0], __popc(grp[j]));   // LDS
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int b = __shfl(base[j], (lane & ~15) + (grp[j] ? __ffs(grp[j]) - 1 : 0), 64);
+        if (hit[j]) {
+          const int pos = b + __popc(grp[j] & ((1u << l15) - 1u));
+          if (pos < a.seg_cap) a.seg[((size_t)qg[j] * a.nsplit + by) * a.seg_cap + pos] = make_key(sc[j], (uint32_t)v[j]);
+        }
       }
     }
+    wq_cnt = 0;
+  };
+  // after every stage: the barrier hands the LDS tile buffer over.  ALL waves empty their queues at the same stage, as
+  // soon as one of them is half full: a wave that flushes alone makes its three siblings wait at the next barrier, and
+  // with four independent triggers the workgroup stalled four times as often (0.64 of 1.8 ms).
+  auto stage_end = [&](bool last) {
+    if (!DENSE && lane == 0) wcnt[wpar][w] = wq_cnt;
     __syncthreads();
-    if (tid == 0) q_cnt = 0;
-    __syncthreads();
+    if (!DENSE) {
+      // the slot read here is rewritten two barriers later at the earliest: every wave sees the same four values
+      const unsigned m01 = wcnt[wpar][0] > wcnt[wpar][1] ? wcnt[wpar][0] : wcnt[wpar][1];
+      const unsigned m23 = wcnt[wpar][2] > wcnt[wpar][3] ? wcnt[wpar][2] : wcnt[wpar][3];
+      wpar ^= 1;
+      if (last || (m01 > m23 ? m01 : m23) >= (unsigned)(WQ - 16)) wave_flush();   // workgroup-uniform decision (a stage adds ~9 columns per wave)
+    }
   };
   auto compute = [&](int buf, int64_t i) {
 #pragma unroll
@@ -377,19 +463,67 @@ __global__ __launch_bounds__(256, 3) void scan_bf16_kernel(ScanArgs a) {
     }
   };
 
-  load_tile(i0);
-  store_tile(0);
+  // two stages in flight through registers (global latency under load is 2-4 stages of MFMA work), two LDS buffers
+  load_tile(stA, i0);
+  store_tile(stA, 0);
+  if (i0 + 1 < i1) load_tile(stA, i0 + 1);
   __syncthreads();
 #pragma unroll 1
-  for (int64_t i = i0; i < i1; ++i) {
-    const int it = (int)((i - i0) & 1);
-    if (i + 1 < i1) load_tile(i + 1);   // in flight during this stage's MFMA work (3 workgroups per CU interleave)
-    compute(it, i);
-    if (i + 1 < i1) store_tile(it ^ 1);
-    __syncthreads();
-    if (!DENSE && q_cnt >= (unsigned)(QCOLS / 2)) flush();  // uniform: q_cnt is read after the barrier
+  for (int64_t i = i0; i < i1; i += 2) {
+    // even phase: buffer 0 = stage i, stA = stage i+1 (in flight)
+    if (i + 2 < i1) load_tile(stB, i + 2);
+    compute(0, i);
+    if (i + 1 < i1) store_tile(stA, 1);
+    stage_end(i + 1 >= i1);
+    if (i + 1 >= i1) break;
+    // odd phase: buffer 1 = stage i+1, stB = stage i+2 (in flight)
+    if (i + 3 < i1) load_tile(stA, i + 3);
+    compute(1, i + 1);
+    if (i + 2 < i1) store_tile(stB, 0);
+    stage_end(i + 2 >= i1);
   }
-  if (!DENSE) flush();
+  if (MODE == 0 && hh == 0) {   // the wave's own LDS atomics are complete (in order): publish the segment fills
+    if (ok0) a.seg_cnt[(size_t)qr0 * a.nsplit + by] = qcntS[ql0];
+    if (ok1) a.seg_cnt[(size_t)qr1 * a.nsplit + by] = qcntS[ql1];
+  }
+  if (MODE == 2) {   // stream = (corpus split, row half): SAMPLE_T key slots each, [nq, 2 * nsplit * SAMPLE_T]
+    const int64_t slot = ((int64_t)by * 2 + hh) * SAMPLE_T;
+#pragma unroll
+    for (int i = 0; i < SAMPLE_T; ++i) {
+      if (ok0) a.cand[(size_t)qr0 * a.cap + slot + i] = make_key(top0[i], 0u);
+      if (ok1) a.cand[(size_t)qr1 * a.cap + slot + i] = make_key(top1[i], 0u);
+    }
+  }
+}
+
+// segments -> the contiguous candidate list of query blockIdx.x (split order, then slot order: deterministic); a
+// segment that overflowed marks the query as overflowed (count > cap => exact re-do)
+__global__ __launch_bounds__(256) void compact_segments_kernel(const uint64_t* __restrict__ seg, const int* __restrict__ seg_cnt,
+                                                               int nsplit, int seg_cap, uint64_t* cand, int64_t cap,
+                                                               int* count, int cs) {
+  __shared__ int off[1025];
+  __shared__ int over;
+  const int64_t q = blockIdx.x;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    int run = 0, ov = 0;
+    for (int s = 0; s < nsplit; ++s) {
+      int c = seg_cnt[q * nsplit + s];
+      if (c > seg_cap) { ov = 1; c = seg_cap; }
+      off[s] = run; run += c;
+    }
+    off[nsplit] = run;
+    over = ov || run > cap;
+    count[q * cs] = over ? (int)(cap + 1) : run;
+  }
+  __syncthreads();
+  if (over) return;
+  for (int s = tid >> 6; s < nsplit; s += 4) {          // one wave per segment
+    const int n = off[s + 1] - off[s];
+    const uint64_t* src = seg + ((size_t)q * nsplit + s) * seg_cap;
+    uint64_t* dst = cand + (size_t)q * cap + off[s];
+    for (int i = tid & 63; i < n; i += 64) dst[i] = src[i];
+  }
 }
 
 // exact f32 re-score of the survivors: 16 lanes per candidate, fixed summation order
@@ -397,7 +531,7 @@ template <int D>
 __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ X, const float* __restrict__ Q,
                                                      uint64_t* cand, int64_t cap, const int* __restrict__ count,
                                                      float* qnorm, int64_t N, const float* __restrict__ kth_approx,
-                                                     float eps_scale) {
+                                                     float eps_scale, int cs) {
   constexpr int PER = D / 16;  // floats per lane
   const int64_t q = blockIdx.x;
   const int tid = threadIdx.x, l16 = tid & 15, grp = tid >> 4;
@@ -417,7 +551,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ X
     // exact score < kth_approx - eps <= T*: it cannot be in the top-k and its row is not fetched (key zeroed).
     cut = kth_approx ? kth_approx[q] - 2.f * eps_scale * sqrtf(s) - 1e-6f : -INFINITY;
   }
-  const int cnt = count[q];
+  const int cnt = count[q * cs];
   const int64_t n = cnt <= cap ? cnt : 0;  // overflowed list: the query is re-done exactly anyway
   uint64_t* keys = cand + (size_t)q * cap;
   for (int64_t i = grp; i < n; i += 16) {
@@ -1095,42 +1229,71 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
   RCCHK(h->scand.reserve(nq * S));
   RCCHK(h->cand.reserve(nq * cap));
   const unsigned qgrid_b = (unsigned)((nq + QBB - 1) / QBB);
+  // small ranks (k = 500: 36): the sample pass keeps SAMPLE_T scores per stream in registers instead of writing all
+  // S scores per query; for larger ranks the truncation would bite, so those keep the dense sample
+  const bool sample_top = two_prec && rank <= 8 * SAMPLE_T;
+  int main_nsplit = 0;
+  int seg_cap = 64;   // per (query, corpus split) segment: 4x the expected survivors, a power of two, set below
+  auto bf16_nsplit = [&](int64_t tiles) -> int {
+    int64_t ns = (3 * RIHIP_NCU + qgrid_b - 1) / qgrid_b;  // 3 resident workgroups per CU (launch bounds)
+    if (ns > tiles) ns = tiles;
+    if (ns < 1) ns = 1;
+    if (ns > 65535) ns = 65535;
+    return (int)ns;
+  };
+  if (two_prec) {
+    const int ns_main = bf16_nsplit((h->N + TRB - 1) / TRB);
+    while ((double)seg_cap < 4.0 * expect / ns_main) seg_cap <<= 1;
+    if ((int64_t)seg_cap > cap) seg_cap = (int)cap;
+  }
+  const int64_t sample_tiles = (S + (two_prec ? TRB : TRS) - 1) / (two_prec ? TRB : TRS);
+  const int64_t cap_s = sample_top ? (int64_t)2 * bf16_nsplit(sample_tiles) * SAMPLE_T : S;  // streams = 2 * nsplit
   auto run_scan = [&](const ScanArgs& args, int64_t tiles) -> int {
     ScanArgs x = args;
     if (two_prec) {
       x.Xb = h->Xb;
-      const int64_t qblocks = qgrid_b;
-      int64_t ns = (3 * RIHIP_NCU + qblocks - 1) / qblocks;  // 3 resident workgroups per CU (launch bounds)
-      if (ns > tiles) ns = tiles;
-      if (ns < 1) ns = 1;
-      if (ns > 65535) ns = 65535;
-      x.nsplit = (int)ns;
+      x.nsplit = bf16_nsplit(tiles);
       x.qgrid = (int)qgrid_b;
+      if (!x.dense) {
+        RIHIP_REQUIRE(x.nsplit <= 1024, RIHIP_ERR_SHAPE, "ip_index: %d corpus splits", x.nsplit);
+        RCCHK(h->seg.reserve(nq * x.nsplit * seg_cap));
+        RCCHK(h->seg_cnt.reserve(nq * x.nsplit));
+        x.seg = h->seg.p; x.seg_cnt = h->seg_cnt.p; x.seg_cap = seg_cap; main_nsplit = x.nsplit;
+      }
       const dim3 grid(qgrid_b * 8u * (unsigned)((x.nsplit + 7) / 8));
-      if (x.dense) {
-        if (d == 32) hipLaunchKernelGGL((scan_bf16_kernel<32, true>), grid, dim3(256), 0, st, x);
-        else if (d == 64) hipLaunchKernelGGL((scan_bf16_kernel<64, true>), grid, dim3(256), 0, st, x);
-        else hipLaunchKernelGGL((scan_bf16_kernel<128, true>), grid, dim3(256), 0, st, x);
+      const int mode = x.dense ? (sample_top ? 2 : 1) : 0;
+      if (mode == 2) {
+        if (d == 32) hipLaunchKernelGGL((scan_bf16_kernel<32, 2>), grid, dim3(256), 0, st, x);
+        else if (d == 64) hipLaunchKernelGGL((scan_bf16_kernel<64, 2>), grid, dim3(256), 0, st, x);
+        else hipLaunchKernelGGL((scan_bf16_kernel<128, 2>), grid, dim3(256), 0, st, x);
+      } else if (mode == 1) {
+        if (d == 32) hipLaunchKernelGGL((scan_bf16_kernel<32, 1>), grid, dim3(256), 0, st, x);
+        else if (d == 64) hipLaunchKernelGGL((scan_bf16_kernel<64, 1>), grid, dim3(256), 0, st, x);
+        else hipLaunchKernelGGL((scan_bf16_kernel<128, 1>), grid, dim3(256), 0, st, x);
       } else {
-        if (d == 32) hipLaunchKernelGGL((scan_bf16_kernel<32, false>), grid, dim3(256), 0, st, x);
-        else if (d == 64) hipLaunchKernelGGL((scan_bf16_kernel<64, false>), grid, dim3(256), 0, st, x);
-        else hipLaunchKernelGGL((scan_bf16_kernel<128, false>), grid, dim3(256), 0, st, x);
+        if (d == 32) hipLaunchKernelGGL((scan_bf16_kernel<32, 0>), grid, dim3(256), 0, st, x);
+        else if (d == 64) hipLaunchKernelGGL((scan_bf16_kernel<64, 0>), grid, dim3(256), 0, st, x);
+        else hipLaunchKernelGGL((scan_bf16_kernel<128, 0>), grid, dim3(256), 0, st, x);
       }
       return check_launch("scan_bf16");
     }
     x.nsplit = pick_nsplit(nq, tiles);
     return dispatch_scan(d, x, dim3(qgrid, x.nsplit), st);
   };
-  hipLaunchKernelGGL(fill_int_kernel, dim3(nqb), dim3(256), 0, st, h->count.p, nq, (int)S);
-  sa.n_virtual = S; sa.row_stride = stride; sa.thr = nullptr; sa.cand = h->scand.p; sa.cap = S; sa.dense = 1;
-  RCCHK(run_scan(sa, (S + (two_prec ? TRB : TRS) - 1) / (two_prec ? TRB : TRS)));
-  fa.cand = h->scand.p; fa.cap = S; fa.mode = 1; fa.rank = rank; fa.thr_out = h->thr.p;
+  sa.n_virtual = S; sa.row_stride = stride; sa.thr = nullptr; sa.cand = h->scand.p; sa.cap = cap_s; sa.dense = 1;
+  if (sample_top) HIPCHK(hipMemsetAsync(h->scand.p, 0, sizeof(uint64_t) * (size_t)(nq * cap_s), st));  // empty streams: key 0
+  RCCHK(run_scan(sa, sample_tiles));
+  hipLaunchKernelGGL(fill_int_kernel, dim3(nqb), dim3(256), 0, st, h->count.p, nq, (int)cap_s);
+  fa.cand = h->scand.p; fa.cap = cap_s; fa.mode = 1; fa.rank = rank; fa.thr_out = h->thr.p;
   RCCHK(launch_finalize(fa, (unsigned)nq, st));
   // ---- pass 1: thresholded scan (atomic append of the rare survivors)
-  hipLaunchKernelGGL(fill_int_kernel, dim3(nqb), dim3(256), 0, st, h->count.p, nq, 0);
+  hipLaunchKernelGGL(fill_int_kernel, dim3((unsigned)((nq * CSTRIDE + 255) / 256)), dim3(256), 0, st, h->count.p, nq * CSTRIDE, 0);
   sa.n_virtual = h->N; sa.row_stride = 1; sa.thr = h->thr.p; sa.cand = h->cand.p; sa.cap = cap; sa.dense = 0;
+  sa.cs = CSTRIDE; fa.count_stride = CSTRIDE;
   RCCHK(run_scan(sa, two_prec ? (h->N + TRB - 1) / TRB : n_tiles));
   if (two_prec) {  // exact f32 re-score of the survivors (keys rewritten in place)
+    hipLaunchKernelGGL(compact_segments_kernel, dim3((unsigned)nq), dim3(256), 0, st, h->seg.p, h->seg_cnt.p, main_nsplit,
+                       seg_cap, h->cand.p, cap, h->count.p, CSTRIDE);
     RCCHK(h->qnorm.reserve(nq));
     RCCHK(h->thr2.reserve(nq));
     {  // k-th largest APPROXIMATE score per query (a lower bound of it: the select stops early): rerank_kernel uses it
@@ -1141,9 +1304,9 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
       RCCHK(launch_finalize(f2, (unsigned)nq, st));
     }
     const float eps_sc = (float)((1.0 / 256.0 + 1.0 / 262144.0) * (double)h->max_norm * 1.001);
-    if (d == 32) hipLaunchKernelGGL((rerank_kernel<32>), dim3((unsigned)nq), dim3(256), 0, st, h->X, Q, h->cand.p, cap, h->count.p, h->qnorm.p, h->N, h->thr2.p, eps_sc);
-    else if (d == 64) hipLaunchKernelGGL((rerank_kernel<64>), dim3((unsigned)nq), dim3(256), 0, st, h->X, Q, h->cand.p, cap, h->count.p, h->qnorm.p, h->N, h->thr2.p, eps_sc);
-    else hipLaunchKernelGGL((rerank_kernel<128>), dim3((unsigned)nq), dim3(256), 0, st, h->X, Q, h->cand.p, cap, h->count.p, h->qnorm.p, h->N, h->thr2.p, eps_sc);
+    if (d == 32) hipLaunchKernelGGL((rerank_kernel<32>), dim3((unsigned)nq), dim3(256), 0, st, h->X, Q, h->cand.p, cap, h->count.p, h->qnorm.p, h->N, h->thr2.p, eps_sc, CSTRIDE);
+    else if (d == 64) hipLaunchKernelGGL((rerank_kernel<64>), dim3((unsigned)nq), dim3(256), 0, st, h->X, Q, h->cand.p, cap, h->count.p, h->qnorm.p, h->N, h->thr2.p, eps_sc, CSTRIDE);
+    else hipLaunchKernelGGL((rerank_kernel<128>), dim3((unsigned)nq), dim3(256), 0, st, h->X, Q, h->cand.p, cap, h->count.p, h->qnorm.p, h->N, h->thr2.p, eps_sc, CSTRIDE);
     fa.thr_chk = h->thr.p; fa.qnorm = h->qnorm.p;
     fa.eps_scale = (float)((1.0 / 256.0 + 1.0 / 262144.0) * (double)h->max_norm * 1.001);
   }
@@ -1225,7 +1388,7 @@ extern "C" int rihip_ip_index_destroy(void* handle) {
   h->cand.release(); h->scand.release(); h->fcand.release(); h->count.release(); h->fail_flags.release();
   h->fail_list.release(); h->n_fail.release(); h->fcount.release(); h->thr.release(); h->thr2.release(); h->fQ.release();
   h->coarse.release(); h->probe_list.release(); h->list_q.release(); h->list_cnt.release(); h->list_qoff.release();
-  h->list_cur.release(); h->work_off.release(); h->plan.release(); h->qnorm.release();
+  h->list_cur.release(); h->work_off.release(); h->plan.release(); h->qnorm.release(); h->seg.release(); h->seg_cnt.release();
   if (h->h_nfail) hipHostFree(h->h_nfail);
   delete h;
   return RIHIP_OK;
