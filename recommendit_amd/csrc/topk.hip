@@ -298,7 +298,13 @@ __global__ __launch_bounds__(256, 3) void scan_bf16_kernel(ScanArgs a) {
   const int64_t per = (n_seq + a.nsplit - 1) / a.nsplit;
   const int64_t i0 = (int64_t)by * per;
   const int64_t i1 = (i0 + per < n_seq) ? i0 + per : n_seq;
-  if (i0 >= i1) return;
+  if (i0 >= i1) {   // a split without rows (nsplit does not divide the stages): its segments are empty, and SAY so
+    if (MODE == 0 && hh == 0) {
+      if (ok0) a.seg_cnt[(size_t)qr0 * a.nsplit + by] = 0;
+      if (ok1) a.seg_cnt[(size_t)qr1 * a.nsplit + by] = 0;
+    }
+    return;
+  }
   if (!DENSE) {   // visible to the flush after the first stage barrier
     if (hh == 0) { thrS[ql0] = ok0 ? th0 : INFINITY; thrS[ql1] = ok1 ? th1 : INFINITY; qcntS[ql0] = 0; qcntS[ql1] = 0; }
   }

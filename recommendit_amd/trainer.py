@@ -60,16 +60,24 @@ class _RowsOpt:
         self.uniq = torch.empty((max_ids,), dtype=torch.int64, device=dev)
         self.Gc = torch.empty((max_ids, self.d), dtype=torch.float32, device=dev)
 
-    def group_reduce(self, ids: torch.Tensor, dX: torch.Tensor, part_ptr: int, st: int) -> None:
+    def group(self, ids: torch.Tensor, st: int) -> None:
+        """sort the step's ids and find the unique rows: needs only the ids, so it can run beside the towers"""
         lib = L.lib()
         B = ids.numel()
         assert B <= self.max_ids
         L.check(lib.rihip_rows_group(ids.data_ptr(), B, self.d, self.table.shape[0], self.uniq.data_ptr(), self.ws.data_ptr(), self.ws.numel(),
                                      st),
                 "rows_group")
-        L.check(lib.rihip_rows_reduce(dX.data_ptr(), B, self.d, self.uniq.data_ptr(), self.ws.data_ptr(),
-                                      self.Gc.data_ptr(), part_ptr, st), "rows_reduce")
         self._B = B
+
+    def reduce(self, dX: torch.Tensor, part_ptr: int, st: int) -> None:
+        """per-unique-row gradient sums (+ their squared-norm partials) of the ids grouped by group()"""
+        L.check(L.lib().rihip_rows_reduce(dX.data_ptr(), self._B, self.d, self.uniq.data_ptr(), self.ws.data_ptr(),
+                                          self.Gc.data_ptr(), part_ptr, st), "rows_reduce")
+
+    def group_reduce(self, ids: torch.Tensor, dX: torch.Tensor, part_ptr: int, st: int) -> None:
+        self.group(ids, st)
+        self.reduce(dX, part_ptr, st)
 
     def adam(self, lr, b1, b2, eps, wd, step, coef_ptr, st, hyper_ptr=None) -> None:
         L.check(L.lib().rihip_adam_rows(self.table.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
@@ -127,6 +135,7 @@ class HipBPRTrainer:
         self._graph = None
         self._dI_work = None
         self._side_stream = torch.cuda.Stream(device=self.dev)
+        self._side_stream2 = torch.cuda.Stream(device=self.dev)
         self._eager_steps = 0  # bench hook: list collecting (start, end) events around every sweep launch
         self.pg = process_group
         self.dist = bool(distributed) or process_group is not None   # collectives are issued iff this is set
@@ -309,6 +318,30 @@ class HipBPRTrainer:
         s0 = (self.seed * 1000003 + self.rank * 7919) & ((1 << 62) - 1)   # + device step counter inside the kernel
         self._I_work = None
         itab, iids = self.itab, item_ids
+        sparse = self.table_opt == "sparse"
+        cur = torch.cuda.current_stream(self.dev)
+        sideA, sideB = self._side_stream, self._side_stream2
+        early_item_group = sparse and not self.dist       # distributed: the owner's id list only exists after the exchange
+        ev_in = None
+        if sparse:
+            ev_in = torch.cuda.Event()
+            ev_in.record(cur)      # inputs + everything of the previous step; recorded BEFORE this step's first launch
+
+        # The id sort / unique-row search (~12 small dependent kernels per table) needs only the ids: it runs on side
+        # streams beside the towers instead of after them (150 us of launch-bound tail per step).  HOST order matters as
+        # much as stream order: each group is ~12 launches = ~70 us of host time, so they are enqueued only once the
+        # host is well ahead of the GPU (after the forward + loss launches / after the user tower's backward).
+        def early_group_user():
+            if sparse:
+                sideA.wait_event(ev_in)
+                with torch.cuda.stream(sideA):
+                    self.uopt.group(user_ids, sideA.cuda_stream)
+
+        def early_group_item():
+            if early_item_group:
+                sideB.wait_event(ev_in)
+                with torch.cuda.stream(sideB):
+                    self.iopt.group(item_ids, sideB.cuda_stream)
         if self.item_rows:
             # row-sharded item table: the rows travel (all-to-all) under the user tower, then the item tower reads the
             # received rows as a [nI,d] staging table indexed by each pair's send slot
@@ -337,8 +370,17 @@ class HipBPRTrainer:
         else:
             self._inbatch(st)
 
+        early_group_user()
         # user tower first: in the multi-GPU stored-G form dI is still being reduce-scattered
         self._bwd(self.utab, user_ids, None, ukeys, self.dU, self.U, self.denU, self.hidU, self.dXu)
+        pp = self.part.data_ptr()
+        o1 = self.np_mlp
+        o2 = o1 + self.np_rows
+        if sparse:   # the user rows' segment sums run beside the item tower's backward
+            sideA.wait_stream(cur)
+            with torch.cuda.stream(sideA):
+                self.uopt.reduce(self.dXu, pp + 8 * o1, sideA.cuda_stream)
+        early_group_item()
         if self._dI_work is not None:
             self._dI_work.wait(); self._dI_work = None
         self._bwd(itab, iids, item_genres, ikeys, self.dI, self.I, self.denI, self.hidI, self.dXi)
@@ -361,30 +403,24 @@ class HipBPRTrainer:
             w_x = all_gather_into(self.dXi_all, self.dXi, self.pg, async_op=True)
             all_reduce_sum_(self.flat_g, self.pg)
             iid, dXi = self.iid_all, self.dXi_all
-        pp = self.part.data_ptr()
         dense = self.table_opt == "dense"
         if not dense:
             L.check(lib.rihip_sumsq(self.flat_g.data_ptr(), self.flat_g.numel(), pp, st), "sumsq")
-        o1 = self.np_mlp
-        o2 = o1 + self.np_rows
-        if self.table_opt == "sparse":
-            # the two tables' group+reduce chains (~10 small dependent kernels each) are independent until the clip
-            # coefficient: the user chain runs on a side stream beside the item chain
-            cur = torch.cuda.current_stream(self.dev)
-            side = self._side_stream
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                self.uopt.group_reduce(user_ids, self.dXu, pp + 8 * o1, side.cuda_stream)
+        if sparse:
             if w_i is not None:
                 w_i.wait()
             if w_x is not None:
                 w_x.wait()
             if iid.numel() > 0:
-                self.iopt.group_reduce(iid, dXi, pp + 8 * o2, st)
+                if early_item_group:
+                    cur.wait_stream(sideB)
+                    self.iopt.reduce(dXi, pp + 8 * o2, st)
+                else:
+                    self.iopt.group_reduce(iid, dXi, pp + 8 * o2, st)
             else:   # this rank owns none of the rows of the step
                 self.part[o2:o2 + self.np_rows].zero_()
                 self.iopt._B = 0
-            cur.wait_stream(side)
+            cur.wait_stream(sideA)
         else:
             # dense tables (ML-1M scale): the table gradients were zeroed by the previous step's Adam launch
             self.uopt.scatter(user_ids, self.dXu, st, zero=False)
@@ -413,9 +449,12 @@ class HipBPRTrainer:
         L.check(lib.rihip_adam_dense(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
                                      self.flat_v.data_ptr(), self.flat_p.numel(), lr, self.b1, self.b2, self.eps,
                                      self.wd, t, cp, hp, st), "adam_dense")
-        self.uopt.adam(lr, self.b1, self.b2, self.eps, self.wd, t, cp, st, hp)
+        sideA.wait_stream(cur)   # clip coefficient + step clock are ready: the two tables update side by side
+        with torch.cuda.stream(sideA):
+            self.uopt.adam(lr, self.b1, self.b2, self.eps, self.wd, t, cp, sideA.cuda_stream, hp)
         if self.iopt._B > 0:
             self.iopt.adam(lr, self.b1, self.b2, self.eps, self.wd, t, cp, st, hp)
+        cur.wait_stream(sideA)   # the next step's towers read the user table
         return self.loss
 
     def _fetch_item_rows(self, item_ids: torch.Tensor, st: int):

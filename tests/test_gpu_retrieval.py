@@ -225,6 +225,23 @@ def test_two_precision_search_equals_all_f32():
         assert set(r1[q]) == set(r2[q]) or np.abs(s1[q, -1] - s1[q, -2]) < 1e-6
 
 
+def test_two_precision_scratch_reuse_across_batch_sizes():
+    """The filter's per-(query, corpus split) segments live in scratch that is reused by later calls with another
+    number of splits; splits that get no rows (the split count does not divide the stages) must still publish an empty
+    segment (regression: stale counts leaked candidates of an earlier batch into the result)."""
+    rng = np.random.RandomState(13)
+    N, d, k = 250000, 128, 500
+    X = fx.unit_rows(rng, N, d)
+    idx = _index(X)
+    Qa, Qb = fx.unit_rows(rng, 1500, d), fx.unit_rows(rng, 200, d)
+    idx.batch_search(Qa, k=k)                      # 6 query blocks -> 128 splits
+    s, r = idx.batch_search(Qb, k=k)               # 1 query block  -> 768 splits, 116 of them empty
+    sel = rng.choice(200, 24, replace=False)
+    _check_topk(s[sel], r[sel] - 1000, Qb[sel], X, k)
+    s2, r2 = idx.batch_search(Qb, k=k)
+    np.testing.assert_array_equal(r2, r)
+
+
 def test_two_precision_dense_survivors_queue_overflow():
     """Small N / large query batch: ~10 % of the 16-score columns hold a survivor, so the per-workgroup LDS queue
     overflows into the out-of-line append path (regression: this shape used to fault)."""
