@@ -179,6 +179,31 @@ int rihip_route_rows(const int64_t* ids, int64_t B, int world, int64_t* sorted_l
 int rihip_gather_rows(const float* table, int64_t n_rows, const int64_t* ids, int64_t n, int d, float* out,
                       int* err_flag, void* stream);
 
+/* ---- LambdaMART training -------------------------------------------------------
+ * Replaces the body of LightGBMRanker.train (src/models/ranker.py:52-155): lgb.train(objective="lambdarank", ...) with
+ * the reference's parameters (defaults below = ranker.py:107-121).  X device f32 [n,F] row-major, y device f32 [n]
+ * (integer relevance grades), groups HOST int32 [ng] (documents per query, in row order; <= 16384 each); the
+ * validation set is optional (NULL / 0): with it, training stops when an eval metric has not improved for
+ * early_stopping_rounds.  model_text receives a malloc'd LightGBM-format text model (free with rihip_free):
+ * rihip_gbdt_create_from_text loads it.  history (host, nullable): [n_rounds][2][n_eval_at] NDCG of train / valid
+ * (valid = NaN without a validation set).  Synchronous.  Algorithm and its NumPy restatement: csrc/gbdt_train.hip,
+ * oracle/lambdamart_np.py (lightgbm itself is not available offline: parity unpinned). */
+typedef struct rihip_lambdamart_params {
+  int num_leaves, n_estimators, min_child_samples, max_bin, truncation_level, early_stopping_rounds, lambdarank_norm,
+      bin_sample;
+  int n_eval_at;
+  int eval_at[8];
+  int n_label_gain;
+  double label_gain[32];
+  double learning_rate, reg_alpha, reg_lambda, feature_fraction, min_sum_hessian, sigmoid;
+  uint64_t seed;
+} rihip_lambdamart_params;
+int rihip_lambdamart_train(const float* X, const float* y, const int32_t* groups, int64_t n, int F, int ng,
+                           const float* Xv, const float* yv, const int32_t* groups_v, int64_t nv, int ngv,
+                           const rihip_lambdamart_params* params, const char* feature_names, char** model_text,
+                           int* best_iteration, int* n_rounds, double* history, void* stream);
+void rihip_free(void* p);
+
 /* ---- inner-product index -------------------------------------------------------------------
  * Replaces faiss.IndexFlatIP / IndexIVFFlat(METRIC_INNER_PRODUCT) behind FAISSIndex
  * (src/models/faiss_index.py:68-74 build, :113/:145 search, :164/:196 write/read).

@@ -1,0 +1,328 @@
+"""NumPy restatement of the LambdaMART trainer (TEST INFRASTRUCTURE).
+
+What the reference trains: ``lgb.train(params, ...)`` with ``objective=lambdarank`` (src/models/ranker.py:86-151:
+num_leaves 63, learning_rate 0.05, min_child_samples 20, colsample_bytree 0.8, reg_alpha 0.1, reg_lambda 0.1,
+label_gain [0,1,3,7,15], eval_at [5,10,20], early stopping 30 rounds on the validation NDCG; ``subsample`` 0.8 is
+inactive in LightGBM without ``bagging_freq``).  The arithmetic lives in lightgbm (>=4.1.0, requirements.txt:3), which is
+third-party and not installed here: **parity unpinned**.  This file restates LightGBM's published algorithm --
+histogram-based leaf-wise GBDT (``SerialTreeLearner``: per-leaf (gradient, hessian, count) histograms over <= 255
+bins per feature, histogram subtraction, gain = ThresholdL1(G)^2/(H+l2), best-first growth) with the lambdarank
+objective (``LambdarankNDCG::GetGradientsForOneQuery``: pairs (i < truncation_level, j > i) with different labels,
+delta NDCG x sigmoid, normalisation by (0.01 + |delta score|) and by log2(1+sum)/sum) -- in the exact form the HIP
+trainer (recommendit_amd/csrc/gbdt_train.hip) implements it, so that the two can be compared tree by tree:
+  * bin upper bounds from a strided sample of <= 200 000 rows (LightGBM: bin_construct_sample_cnt), midpoints between
+    neighbouring distinct values, equal-frequency cuts when a feature has more than max_bin distinct values;
+  * gradients / hessians are quantised to integers (2^20 levels of the largest magnitude) before they enter the
+    histograms, so every histogram sum is an integer and independent of the summation order: splits are bit-exact;
+  * feature_fraction picks the features of a tree with a counter-based generator (splitmix64 of seed, tree, feature).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+K_EPS = 1e-15
+QLEVELS = float(1 << 20)
+MASK64 = (1 << 64) - 1
+
+
+def splitmix64(x: int) -> int:
+    x = (x + 0x9E3779B97F4A7C15) & MASK64
+    x ^= x >> 30
+    x = (x * 0xBF58476D1CE4E5B9) & MASK64
+    x ^= x >> 27
+    x = (x * 0x94D049BB133111EB) & MASK64
+    x ^= x >> 31
+    return x
+
+
+def default_params(**kw) -> Dict:
+    p = dict(num_leaves=63, n_estimators=500, learning_rate=0.05, min_child_samples=20, max_bin=255,
+             truncation_level=30, early_stopping_rounds=30, eval_at=[5, 10, 20], reg_alpha=0.1, reg_lambda=0.1,
+             feature_fraction=0.8, min_sum_hessian=1e-3, sigmoid=1.0, label_gain=[0, 1, 3, 7, 15], seed=2,
+             lambdarank_norm=True, bin_sample=200000)
+    p.update(kw)
+    return p
+
+
+# ------------------------------------------------------------------ binning
+def find_bin_bounds(X: np.ndarray, max_bin: int, bin_sample: int) -> List[np.ndarray]:
+    n = X.shape[0]
+    step = max(1, (n + bin_sample - 1) // bin_sample)
+    S = X[::step]
+    out = []
+    for f in range(X.shape[1]):
+        v = np.sort(S[:, f].astype(np.float64))
+        v = v[~np.isnan(v)]
+        u, c = np.unique(v, return_counts=True)
+        if u.size <= 1:
+            out.append(np.array([np.inf]))
+            continue
+        if u.size <= max_bin:
+            ub = (u[:-1] + u[1:]) * 0.5
+        else:   # equal-frequency cuts on the cumulative counts, each cut placed between two distinct values
+            cum = np.cumsum(c)
+            tot = cum[-1]
+            cuts, last = [], -1
+            for b in range(1, max_bin):
+                i = int(np.searchsorted(cum, (tot * b + max_bin - 1) // max_bin, side="left"))
+                i = min(i, u.size - 2)
+                if i > last:
+                    cuts.append(i)
+                    last = i
+            ub = np.array([(u[i] + u[i + 1]) * 0.5 for i in cuts])
+        out.append(np.concatenate([ub, [np.inf]]))
+    return out
+
+
+def bin_matrix(X: np.ndarray, bounds: List[np.ndarray]) -> np.ndarray:
+    B = np.zeros(X.shape, dtype=np.uint8)
+    for f, ub in enumerate(bounds):
+        x = X[:, f].astype(np.float64)
+        x = np.where(np.isnan(x), 0.0, x)
+        B[:, f] = np.searchsorted(ub, x, side="left").astype(np.uint8)   # first bin with x <= upper bound
+    return B
+
+
+# ------------------------------------------------------------------ lambdarank objective
+def _max_dcg(labels: np.ndarray, k: int, gain: np.ndarray) -> float:
+    g = np.sort(gain[labels.astype(np.int64)])[::-1][:k]
+    return float((g / np.log2(np.arange(g.size) + 2.0)).sum())
+
+
+def lambdarank_grads(scores: np.ndarray, labels: np.ndarray, groups: Sequence[int], p: Dict) -> Tuple[np.ndarray, np.ndarray]:
+    gain = np.asarray(p["label_gain"], dtype=np.float64)
+    sig, T = float(p["sigmoid"]), int(p["truncation_level"])
+    lam = np.zeros(scores.shape, dtype=np.float64)
+    hes = np.zeros(scores.shape, dtype=np.float64)
+    b = 0
+    for cnt in groups:
+        s = scores[b:b + cnt].astype(np.float64)
+        lab = labels[b:b + cnt].astype(np.int64)
+        mx = _max_dcg(lab, T, gain)
+        inv = 1.0 / mx if mx > 0 else 0.0
+        order = np.argsort(-s, kind="stable")                 # ties keep the original order
+        ss, ll = s[order], lab[order]
+        disc = 1.0 / np.log2(np.arange(cnt) + 2.0)
+        gl = gain[ll]
+        l_sorted = np.zeros(cnt)
+        h_sorted = np.zeros(cnt)
+        norm = bool(p["lambdarank_norm"])
+        best, worst = ss[0], ss[-1]
+        sum_l = 0.0
+        for i in range(min(cnt - 1, T)):
+            j = np.arange(i + 1, cnt)
+            m = ll[j] != ll[i]
+            if not m.any():
+                continue
+            j = j[m]
+            hi_is_i = ll[i] > ll[j]
+            ds = np.where(hi_is_i, ss[i] - ss[j], ss[j] - ss[i])          # high score - low score
+            dn = np.abs(gl[i] - gl[j]) * np.abs(disc[i] - disc[j]) * inv
+            if norm and best != worst:
+                dn = dn / (0.01 + np.abs(ds))
+            rho = 1.0 / (1.0 + np.exp(sig * ds))
+            pl = -sig * dn * rho                                           # p_lambda (<= 0)
+            ph = sig * sig * dn * rho * (1.0 - rho)
+            # high gets +p_lambda, low gets -p_lambda
+            l_sorted[i] += np.where(hi_is_i, pl, -pl).sum()
+            np.add.at(l_sorted, j, np.where(hi_is_i, -pl, pl))
+            h_sorted[i] += ph.sum()
+            np.add.at(h_sorted, j, ph)
+            sum_l += float((-2.0 * pl).sum())
+        if norm and sum_l > 0:
+            nf = np.log2(1.0 + sum_l) / sum_l
+            l_sorted *= nf
+            h_sorted *= nf
+        lam[b + order] = l_sorted
+        hes[b + order] = h_sorted
+        b += cnt
+    return lam, hes
+
+
+def quantize(g: np.ndarray, h: np.ndarray) -> Tuple[np.ndarray, np.ndarray, float, float]:
+    gm, hm = float(np.abs(g).max()), float(h.max())
+    sg = QLEVELS / gm if gm > 0 else 0.0
+    sh = QLEVELS / hm if hm > 0 else 0.0
+    return np.rint(g * sg).astype(np.int64), np.rint(h * sh).astype(np.int64), sg, sh
+
+
+def ndcg_at(scores: np.ndarray, labels: np.ndarray, groups: Sequence[int], ks: Sequence[int], gain: np.ndarray) -> List[float]:
+    tot = np.zeros(len(ks))
+    b = 0
+    for cnt in groups:
+        s, lab = scores[b:b + cnt], labels[b:b + cnt].astype(np.int64)
+        order = np.argsort(-s.astype(np.float64), kind="stable")
+        g = gain[lab[order]]
+        for t, k in enumerate(ks):
+            mx = _max_dcg(lab, k, gain)
+            if mx <= 0:
+                tot[t] += 1.0
+            else:
+                kk = min(k, cnt)
+                tot[t] += float((g[:kk] / np.log2(np.arange(kk) + 2.0)).sum()) / mx
+        b += cnt
+    return (tot / len(groups)).tolist()
+
+
+# ------------------------------------------------------------------ tree learner
+def _thr_l1(g: float, l1: float) -> float:
+    return np.sign(g) * max(abs(g) - l1, 0.0)
+
+
+def _leaf_gain(G: float, H: float, l1: float, l2: float) -> float:
+    t = _thr_l1(G, l1)
+    return t * t / (H + l2)
+
+
+def _best_split(hist: np.ndarray, nb: Sequence[int], used: np.ndarray, sg: float, sh: float, p: Dict):
+    """hist int64 [F, 256, 3] (gq, hq, count) -> (gain, feature, bin, GLq, HLq, CL) or None.  Left = bins <= bin."""
+    l1, l2 = float(p["reg_alpha"]), float(p["reg_lambda"])
+    tot = hist[0].sum(0) if hist.shape[0] else np.zeros(3, np.int64)
+    best = None
+    for f in range(hist.shape[0]):
+        if not used[f] or nb[f] < 2:
+            continue
+        tq = hist[f, :nb[f]].sum(0)
+        G, H, Cn = tq[0] / sg if sg else 0.0, tq[1] / sh if sh else 0.0, int(tq[2])
+        parent = _leaf_gain(G, H, l1, l2)
+        cg = ch = cc = 0
+        for b in range(nb[f] - 1):
+            cg += int(hist[f, b, 0]); ch += int(hist[f, b, 1]); cc += int(hist[f, b, 2])
+            GL, HL = cg / sg if sg else 0.0, ch / sh if sh else 0.0
+            GR, HR, CR = G - GL, H - HL, Cn - cc
+            if cc < p["min_child_samples"] or CR < p["min_child_samples"]:
+                continue
+            if HL < p["min_sum_hessian"] or HR < p["min_sum_hessian"]:
+                continue
+            gain = _leaf_gain(GL, HL, l1, l2) + _leaf_gain(GR, HR, l1, l2) - parent
+            if gain > K_EPS and (best is None or gain > best[0]):   # first maximum in (feature, bin) order wins ties
+                best = (gain, f, b, cg, ch, cc)
+    del tot
+    return best
+
+
+def train(X: np.ndarray, y: np.ndarray, groups: Sequence[int], params: Optional[Dict] = None,
+          Xv: Optional[np.ndarray] = None, yv: Optional[np.ndarray] = None, groups_v: Optional[Sequence[int]] = None,
+          feature_names: Optional[List[str]] = None) -> Dict:
+    p = default_params(**(params or {}))
+    n, F = X.shape
+    gain_tab = np.asarray(p["label_gain"], dtype=np.float64)
+    bounds = find_bin_bounds(X, p["max_bin"], p["bin_sample"])
+    nb = [len(b) for b in bounds]
+    Xb = bin_matrix(X, bounds)
+    Xvb = bin_matrix(Xv, bounds) if Xv is not None else None
+    scores = np.zeros(n)
+    vscores = np.zeros(len(Xv)) if Xv is not None else None
+    trees, history = [], []
+    best_val, best_it, since = None, 0, None
+    n_used = max(1, int(F * p["feature_fraction"] + 0.5)) if p["feature_fraction"] < 1.0 else F
+    for it in range(p["n_estimators"]):
+        lam, hes = lambdarank_grads(scores, y, groups, p)
+        gq, hq, sg, sh = quantize(lam, hes)
+        # features of this tree: the n_used smallest hashes
+        hv = np.array([splitmix64(splitmix64(p["seed"] + 1000003 * it) ^ f) for f in range(F)], dtype=np.uint64)
+        used = np.zeros(F, dtype=bool)
+        used[np.argsort(hv, kind="stable")[:n_used]] = True
+        leaf_rows = {0: np.arange(n)}
+        hists = {}
+
+        def hist_of(rows):
+            h = np.zeros((F, 256, 3), dtype=np.int64)
+            for f in range(F):
+                np.add.at(h[f, :, 0], Xb[rows, f], gq[rows])
+                np.add.at(h[f, :, 1], Xb[rows, f], hq[rows])
+                np.add.at(h[f, :, 2], Xb[rows, f], 1)
+            return h
+
+        hists[0] = hist_of(leaf_rows[0])
+        cand = {0: _best_split(hists[0], nb, used, sg, sh, p)}
+        nodes = []          # (feature, bin, left, right, gain, count, Gq, Hq) ; children >=0 node, <0 ~leaf
+        leaf_parent = {0: None}
+        n_leaves = 1
+        while n_leaves < p["num_leaves"]:
+            live = [(v[0], -l) for l, v in cand.items() if v is not None]
+            if not live:
+                break
+            _, negl = max(live)                         # largest gain; ties -> smallest leaf index
+            leaf = -negl
+            gain, f, b, _, _, _ = cand.pop(leaf)
+            rows = leaf_rows.pop(leaf)
+            go_left = Xb[rows, f] <= b
+            lrows, rrows = rows[go_left], rows[~go_left]
+            node = len(nodes)
+            tq = hists[leaf][f, :nb[f]].sum(0)
+            nodes.append([f, b, ~leaf, ~n_leaves, gain, len(rows), int(tq[0]), int(tq[1])])
+            par = leaf_parent[leaf]
+            if par is not None:
+                nodes[par[0]][2 + par[1]] = node
+            new_leaf = n_leaves
+            leaf_rows[leaf], leaf_rows[new_leaf] = lrows, rrows
+            leaf_parent[leaf], leaf_parent[new_leaf] = (node, 0), (node, 1)
+            ph = hists.pop(leaf)
+            small, big = (leaf, new_leaf) if len(lrows) <= len(rrows) else (new_leaf, leaf)
+            hists[small] = hist_of(leaf_rows[small])
+            hists[big] = ph - hists[small]
+            n_leaves += 1
+            for l in (leaf, new_leaf):
+                cand[l] = _best_split(hists[l], nb, used, sg, sh, p) if len(leaf_rows[l]) >= 2 * p["min_child_samples"] else None
+        # leaf values from the (quantised) sums
+        leaf_value = np.zeros(n_leaves)
+        leaf_count = np.zeros(n_leaves, dtype=np.int64)
+        for l, rows in leaf_rows.items():
+            G = gq[rows].sum() / sg if sg else 0.0
+            H = hq[rows].sum() / sh if sh else 0.0
+            leaf_value[l] = -_thr_l1(G, p["reg_alpha"]) / (H + p["reg_lambda"]) * p["learning_rate"]
+            leaf_count[l] = len(rows)
+            scores[rows] += leaf_value[l]
+        tree = dict(num_leaves=n_leaves, split_feature=np.array([nd[0] for nd in nodes], np.int64),
+                    split_bin=np.array([nd[1] for nd in nodes], np.int64),
+                    threshold=np.array([bounds[nd[0]][nd[1]] for nd in nodes], np.float64),
+                    left_child=np.array([nd[2] for nd in nodes], np.int64),
+                    right_child=np.array([nd[3] for nd in nodes], np.int64),
+                    split_gain=np.array([nd[4] for nd in nodes], np.float64), leaf_value=leaf_value,
+                    leaf_count=leaf_count, decision_type=np.full(len(nodes), 2, np.int64), num_cat=0, shrinkage=p["learning_rate"])
+        trees.append(tree)
+        rec = {"train": ndcg_at(scores, y, groups, p["eval_at"], gain_tab)}
+        if Xvb is not None:
+            vscores += predict_tree_binned(tree, Xvb)
+            rec["valid"] = ndcg_at(vscores, yv, groups_v, p["eval_at"], gain_tab)
+            cur = rec["valid"]
+            if best_val is None:
+                best_val, since, best_it = list(cur), [0] * len(cur), it + 1
+            else:
+                for t, v in enumerate(cur):
+                    if v > best_val[t]:
+                        best_val[t], since[t] = v, 0
+                        if t == 0:
+                            best_it = it + 1
+                    else:
+                        since[t] += 1
+            history.append(rec)
+            if max(since) >= p["early_stopping_rounds"]:
+                break
+        else:
+            history.append(rec)
+            best_it = it + 1
+    names = feature_names or [f"Column_{i}" for i in range(F)]
+    return dict(feature_names=names, max_feature_idx=F - 1, num_class=1, num_tree_per_iteration=1, average_output=False,
+                objective="lambdarank", trees=trees, best_iteration=best_it, history=history, bounds=bounds)
+
+
+def predict_tree_binned(tree: Dict, Xb: np.ndarray) -> np.ndarray:
+    out = np.zeros(Xb.shape[0])
+    if tree["num_leaves"] == 1:
+        return out + tree["leaf_value"][0]
+    node = np.zeros(Xb.shape[0], dtype=np.int64)
+    active = np.ones(Xb.shape[0], dtype=bool)
+    while active.any():
+        idx = np.nonzero(active)[0]
+        nd = node[idx]
+        left = Xb[idx, tree["split_feature"][nd]] <= tree["split_bin"][nd]
+        nxt = np.where(left, tree["left_child"][nd], tree["right_child"][nd])
+        node[idx] = nxt
+        done = nxt < 0
+        out[idx[done]] = tree["leaf_value"][~nxt[done]]
+        active[idx[done]] = False
+    return out

@@ -94,6 +94,9 @@ SIGNATURES = {
     "rihip_gbdt_feature_names": (c_i64, [vp, C.c_char_p, c_i64]),
     "rihip_gbdt_feature_importance": (C.c_int, [vp, C.c_int, vp]),
     "rihip_gbdt_predict": (C.c_int, [vp, vp, c_i64, C.c_int, vp, vp]),
+    "rihip_lambdamart_train": (C.c_int, [vp, vp, vp, c_i64, C.c_int, C.c_int, vp, vp, vp, c_i64, C.c_int, vp, C.c_char_p,
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int), vp, vp]),
+    "rihip_free": (None, [vp]),
     "rihip_sample_negatives": (C.c_int, [vp, c_i64, vp, c_i64, vp, c_i64, c_i64, C.c_uint64, C.c_int, vp, vp, vp]),
     "rihip_rank_features_widths": (C.c_int, [vp, vp, vp]),
     "rihip_rank_features_build": (C.c_int, [vp, c_i64, vp, c_i64, vp, vp, c_i64, C.c_int, vp, C.c_int, vp, vp]),
@@ -116,6 +119,16 @@ def lib() -> C.CDLL:
             fn.argtypes = args
         _lib = l
     return _lib
+
+
+class LambdamartParams(C.Structure):
+    """mirror of rihip_lambdamart_params (include/recommendit_hip.h)"""
+    _fields_ = [("num_leaves", C.c_int), ("n_estimators", C.c_int), ("min_child_samples", C.c_int), ("max_bin", C.c_int),
+                ("truncation_level", C.c_int), ("early_stopping_rounds", C.c_int), ("lambdarank_norm", C.c_int),
+                ("bin_sample", C.c_int), ("n_eval_at", C.c_int), ("eval_at", C.c_int * 8), ("n_label_gain", C.c_int),
+                ("label_gain", C.c_double * 32), ("learning_rate", C.c_double), ("reg_alpha", C.c_double),
+                ("reg_lambda", C.c_double), ("feature_fraction", C.c_double), ("min_sum_hessian", C.c_double),
+                ("sigmoid", C.c_double), ("seed", C.c_uint64)]
 
 
 class RihipError(RuntimeError):

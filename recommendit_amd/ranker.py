@@ -2,9 +2,11 @@
 
 Mirrors the reference's src/models/ranker.py (:23-249).  ``load`` parses the LightGBM *text*
 model in C++ (rihip_gbdt_load_text) and ``predict`` walks the forest on the GPU, returning the
-raw lambdarank score as float64 like ``Booster.predict`` (ranker.py:174).  ``train``/``save``
-are LightGBM's CPU trainer and stay delegated to the real package when it is importable
-(train is out of scope).
+raw lambdarank score as float64 like ``Booster.predict`` (ranker.py:174).  ``train`` runs the
+library's own LambdaMART trainer on the GPU (csrc/gbdt_train.hip: LightGBM's published histogram /
+leaf-wise / lambdarank algorithm restated) with the reference's parameters, or --
+``backend="lightgbm"``, the default when the real package is importable -- delegates to lightgbm
+like the reference does.  Either way the trained forest is served by the HIP predictor.
 """
 from __future__ import annotations
 
@@ -89,9 +91,16 @@ class LightGBMRanker:
         self._trained = False
         self._text: Optional[str] = None
 
-    # -- training stays LightGBM's CPU trainer (ranker.py:52-155) -------------------------------
+    # -- training (ranker.py:52-155) -----------------------------------------------------------
     def train(self, train_df: pd.DataFrame, feature_cols: List[str], label_col: str = "label",
-              query_col: str = "query_id", valid_df: Optional[pd.DataFrame] = None, verbose_eval: int = 50):
+              query_col: str = "query_id", valid_df: Optional[pd.DataFrame] = None, verbose_eval: int = 50,
+              backend: Optional[str] = None, seed: int = 2):
+        """backend: "hip" = the library's GPU trainer, "lightgbm" = the real package (as the reference), None = lightgbm
+        when importable, else hip.  Returns the evals_result dict of lgb.record_evaluation:
+        {"train": {"ndcg@5": [...], ...}, "valid": {...}}."""
+        backend = backend or ("lightgbm" if LGB_AVAILABLE else "hip")
+        if backend == "hip":
+            return self._train_hip(train_df, feature_cols, label_col, query_col, valid_df, verbose_eval, seed)
         if not LGB_AVAILABLE:
             raise ImportError("lightgbm is required for training. Install with: pip install lightgbm "
                               "(load()/predict() do not need it)")
@@ -127,6 +136,58 @@ class LightGBMRanker:
         self.model.best_iteration = booster.best_iteration
         self._trained = True
         return evals_result
+
+    def _train_hip(self, train_df, feature_cols, label_col, query_col, valid_df, verbose_eval, seed):
+        lib = L.lib()
+        self.feature_names = list(feature_cols)
+        dev = L.device()
+
+        def pack(df):
+            X = torch.from_numpy(np.ascontiguousarray(df[feature_cols].values.astype(np.float32))).to(dev)
+            y = torch.from_numpy(np.ascontiguousarray(df[label_col].values.astype(np.float32))).to(dev)
+            g = np.ascontiguousarray(df.groupby(query_col, sort=False).size().values.astype(np.int32))
+            return X, y, g
+
+        X, y, g = pack(train_df)
+        Xv = yv = gv = None
+        if valid_df is not None:
+            Xv, yv, gv = pack(valid_df)
+        prm = L.LambdamartParams()
+        prm.num_leaves, prm.n_estimators, prm.learning_rate = self.num_leaves, self.n_estimators, self.learning_rate
+        prm.min_child_samples, prm.max_bin, prm.truncation_level, prm.early_stopping_rounds = 20, 255, 30, 30
+        prm.lambdarank_norm, prm.bin_sample = 1, 200000
+        prm.reg_alpha, prm.reg_lambda, prm.feature_fraction, prm.min_sum_hessian, prm.sigmoid = 0.1, 0.1, 0.8, 1e-3, 1.0
+        prm.seed = seed
+        prm.n_eval_at = len(self.eval_at)
+        for i, k in enumerate(self.eval_at):
+            prm.eval_at[i] = int(k)
+        gains = [0, 1, 3, 7, 15]                                                     # ranker.py:118
+        prm.n_label_gain = len(gains)
+        for i, v in enumerate(gains):
+            prm.label_gain[i] = float(v)
+        nk = len(self.eval_at)
+        hist = np.full((self.n_estimators, 2, nk), np.nan, dtype=np.float64)
+        text_p, best_it, rounds = C.c_void_p(), C.c_int(0), C.c_int(0)
+        logger.info("Training LambdaMART ranker: %d samples, %d features, %d queries", len(train_df), len(feature_cols), len(g))
+        L.check(lib.rihip_lambdamart_train(X.data_ptr(), y.data_ptr(), g.ctypes.data, X.shape[0], X.shape[1], len(g),
+                                           None if Xv is None else Xv.data_ptr(), None if yv is None else yv.data_ptr(),
+                                           None if gv is None else gv.ctypes.data, 0 if Xv is None else Xv.shape[0],
+                                           0 if gv is None else len(gv), C.byref(prm), " ".join(feature_cols).encode(),
+                                           C.byref(text_p), C.byref(best_it), C.byref(rounds), hist.ctypes.data,
+                                           L.stream_ptr()), "lambdamart_train")
+        try:
+            self._text = C.string_at(text_p.value).decode()
+        finally:
+            lib.rihip_free(text_p)
+        self._load_text(self._text)
+        self.model.best_iteration = int(best_it.value)
+        self._trained = True
+        r = int(rounds.value)
+        res: Dict = {"train": {f"ndcg@{k}": hist[:r, 0, t].tolist() for t, k in enumerate(self.eval_at)}}
+        if valid_df is not None:
+            res["valid"] = {f"ndcg@{k}": hist[:r, 1, t].tolist() for t, k in enumerate(self.eval_at)}
+        logger.info("Training complete. Best iteration: %d", self.model.best_iteration)
+        return res
 
     def _load_text(self, text: str) -> None:
         h = C.c_void_p()

@@ -150,3 +150,27 @@ def test_g7_metric_known_answers():
     assert abs(M.mrr([4, 1, 2], [1, 2]) - 0.5) < 1e-6
     assert M.mrr([4, 5, 6], [1, 2, 3]) == 0.0
     assert abs(M.coverage([[1, 2, 3], [4, 5, 6], [1, 7, 8]], 10) - 0.8) < 1e-6
+
+
+def test_lambdamart_oracle_learns_and_is_deterministic():
+    """oracle/lambdamart_np.py (the restatement the HIP LambdaMART trainer is pinned to): NDCG rises on a learnable set,
+    two runs give identical trees, lambdas of a two-document query have the closed form."""
+    from oracle import lambdamart_np as LM
+    rng = np.random.RandomState(0)
+    F, groups = 6, [25] * 40
+    n = sum(groups)
+    X = rng.randn(n, F).astype(np.float32)
+    y = (X[:, 0] + 0.5 * X[:, 1] + 0.3 * rng.randn(n) > 0.8).astype(np.float32)
+    p = dict(num_leaves=7, n_estimators=8, learning_rate=0.2, eval_at=[5], min_child_samples=5)
+    a = LM.train(X, y, groups, p)
+    b = LM.train(X, y, groups, p)
+    h = [r["train"][0] for r in a["history"]]
+    assert h[-1] > h[0] + 0.05 and h[-1] > 0.8
+    for ta, tb in zip(a["trees"], b["trees"]):
+        np.testing.assert_array_equal(ta["split_feature"], tb["split_feature"])
+        np.testing.assert_array_equal(ta["leaf_value"], tb["leaf_value"])
+    # one relevant + one irrelevant document, equal scores: rho = 1/2, delta NDCG = (1 - 1/log2(3)) / 1
+    lam, hes = LM.lambdarank_grads(np.zeros(2), np.array([1.0, 0.0]), [2], LM.default_params(lambdarank_norm=False))
+    d = 1.0 - 1.0 / np.log2(3.0)
+    np.testing.assert_allclose(lam, [-0.5 * d, 0.5 * d], rtol=1e-12)
+    np.testing.assert_allclose(hes, [0.25 * d, 0.25 * d], rtol=1e-12)
