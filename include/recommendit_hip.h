@@ -268,6 +268,10 @@ int rihip_rank_features_widths(int* user_width, int* item_width, int* n_canonica
 int rihip_rank_features_build(const double* user_tab, int64_t n_user_rows, const double* item_tab,
                               int64_t n_item_rows, const int64_t* user_ids, const int64_t* cand_ids, int64_t nq,
                               int kc, const int* col_map, int nf, float* X, void* stream);
+/* nlargest(k, "score") of every request (src/serving/recommender.py:346): scores f64 [nq,kc] (ranker output), cand i64
+ * [nq,kc] (-1 = padding, ranked last), retrieval_scores f32 [nq,kc]; outputs [nq,k], ties keep the retrieval order. */
+int rihip_rank_topk(const double* scores, const int64_t* cand, const float* retrieval_scores, int64_t nq, int kc, int k,
+                    int64_t* out_ids, double* out_scores, float* out_retrieval_scores, void* stream);
 
 /* ---- negative sampler -----------------------------------------------------------------------
  * Replaces UserItemDataset._sample_negative (src/training/train_embeddings.py:58-63) for a batch: neg_out[i] =

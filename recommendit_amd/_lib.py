@@ -99,6 +99,7 @@ SIGNATURES = {
     "rihip_free": (None, [vp]),
     "rihip_sample_negatives": (C.c_int, [vp, c_i64, vp, c_i64, vp, c_i64, c_i64, C.c_uint64, C.c_int, vp, vp, vp]),
     "rihip_rank_features_widths": (C.c_int, [vp, vp, vp]),
+    "rihip_rank_topk": (C.c_int, [vp, vp, vp, c_i64, C.c_int, C.c_int, vp, vp, vp, vp]),
     "rihip_rank_features_build": (C.c_int, [vp, c_i64, vp, c_i64, vp, vp, c_i64, C.c_int, vp, C.c_int, vp, vp]),
 }
 

@@ -52,7 +52,72 @@ __global__ __launch_bounds__(256) void rank_features_kernel(const double* __rest
   X[i] = v;
 }
 
+// final stage of the serving chain: DataFrame.nlargest(k, "score") (src/serving/recommender.py:346) for every request of
+// a batch -- the k best ranker scores, ties keep the retrieval order, padded candidates (id < 0) last -- in one launch
+// instead of the where / sort / gather sequence of tensor ops (5 dependent launches per batch)
+__global__ __launch_bounds__(256) void rank_topk_kernel(const double* __restrict__ scores, const int64_t* __restrict__ cand,
+                                                        const float* __restrict__ rs, int kc, int k, int P,
+                                                        int64_t* out_ids, double* out_scores, float* out_rs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+  unsigned long long* key = reinterpret_cast<unsigned long long*>(sm);       // [P] orderable score (larger = better)
+  unsigned short* idx = reinterpret_cast<unsigned short*>(key + P);           // [P]
+  const int64_t q = blockIdx.x;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < P; i += 256) {
+    unsigned long long kk = 0ull;   // below every real score, -inf included
+    if (i < kc) {
+      const double v = cand[q * kc + i] >= 0 ? scores[q * kc + i] : -INFINITY;
+      unsigned long long u = (unsigned long long)__double_as_longlong(v);
+      kk = (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+      if (kk == 0ull) kk = 1ull;
+    }
+    key[i] = kk; idx[i] = (unsigned short)i;
+  }
+  __syncthreads();
+  for (int size = 2; size <= P; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = tid; i < P / 2; i += 256) {
+        const int lo = (i / stride) * (stride << 1) + (i % stride), hi = lo + stride;
+        const bool desc = ((lo & size) == 0);
+        const unsigned long long a = key[lo], b = key[hi];
+        const unsigned short ia = idx[lo], ib = idx[hi];
+        const bool a_first = a > b || (a == b && ia < ib);   // total order: score desc, then retrieval position asc
+        if (desc ? !a_first : a_first) { key[lo] = b; key[hi] = a; idx[lo] = ib; idx[hi] = ia; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < k; i += 256) {
+    const int j = idx[i];
+    const bool ok = i < kc && j < kc;
+    out_ids[q * k + i] = ok ? cand[q * kc + j] : -1;
+    out_scores[q * k + i] = ok ? (cand[q * kc + j] >= 0 ? scores[q * kc + j] : -INFINITY) : -INFINITY;
+    out_rs[q * k + i] = ok ? rs[q * kc + j] : -INFINITY;
+  }
+}
+
 }  // namespace
+
+extern "C" int rihip_rank_topk(const double* scores, const int64_t* cand, const float* retrieval_scores, int64_t nq, int kc,
+                               int k, int64_t* out_ids, double* out_scores, float* out_retrieval_scores, void* stream) {
+  RIHIP_REQUIRE(scores && cand && retrieval_scores && out_ids && out_scores && out_retrieval_scores, RIHIP_ERR_ARG,
+                "rank_topk: null pointer");
+  RIHIP_REQUIRE(nq >= 0 && kc >= 1 && kc <= 8192 && k >= 1, RIHIP_ERR_ARG, "rank_topk: kc=%d (1..8192), k=%d", kc, k);
+  if (nq == 0) return RIHIP_OK;
+  int P = 64;
+  while (P < kc || P < k) P <<= 1;
+  RIHIP_REQUIRE(P <= 8192, RIHIP_ERR_ARG, "rank_topk: k=%d too large", k);
+  const size_t lds = (size_t)P * 10;
+  static bool granted = false;
+  if (!granted) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rank_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 10);
+    granted = true;
+  }
+  hipLaunchKernelGGL(rank_topk_kernel, dim3((unsigned)nq), dim3(256), lds, (hipStream_t)stream, scores, cand, retrieval_scores,
+                     kc, k, P, out_ids, out_scores, out_retrieval_scores);
+  RIHIP_CHECK_LAUNCH();
+  return RIHIP_OK;
+}
 
 extern "C" int rihip_rank_features_widths(int* user_width, int* item_width, int* n_canonical) {
   if (user_width) *user_width = UW;

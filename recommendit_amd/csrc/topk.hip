@@ -591,6 +591,7 @@ struct FinArgs {
   int rank;              // mode 1: r
   float* out_scores;     // [nq_out, k]
   int64_t* out_rows;     // [nq_out, k]
+  uint64_t* out_keys;    // mode 0, optional: write the k best KEYS (0-padded) instead of scores/rows (hierarchical select)
   const int* out_slot;   // optional: where query i's results go (fallback), or null
   float* thr_out;        // mode 1
   int* fail_flags;       // [nq] mode 0: 1 if count<need_min or count>cap
@@ -713,6 +714,10 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
     if (sk < a.thr_chk[q] + a.eps_scale * a.qnorm[q] + 2e-6f) fail = true;
   }
   if (a.fail_flags && tid == 0) a.fail_flags[q] = fail ? 1 : 0;
+  if (a.out_keys) {
+    for (int i = tid; i < a.k; i += 256) a.out_keys[oslot * a.k + i] = i < k_sel ? sbuf[i] : 0ull;
+    return;
+  }
   for (int i = tid; i < a.k; i += 256) {
     float sc = -INFINITY;
     int64_t row = -1;
@@ -768,7 +773,8 @@ struct LmArgs {
   int nprobe;                // list_q holds pair indices q * nprobe + p
   int count_stride;          // ints between two queries' candidate counters (32 = one 128-B line each: same-line
                              // atomics serialise in L2)
-  int64_t dense_cap;         // > 0: threshold-sample pass, cand = [nq*nprobe, dense_cap] pre-zeroed key slots
+  int64_t dense_cap;         // > 0: dense slots, cand = [nq*nprobe, dense_cap] pre-zeroed keys (no atomics)
+  int dense_ids;             // dense slots carry the original row id (unfiltered search) instead of 0 (threshold sample)
 };
 
 // coarse scores cs[q, c] = <Q[q], C[c]> on exact-f32 MFMA (4 waves x 32 register-stationary queries, centroid tiles
@@ -996,7 +1002,8 @@ __global__ __launch_bounds__(256, 2) void ivf_scan_lm_kernel(LmArgs a) {
       for (int r = 0; r < 16; ++r) {
         const int rr = acc_row(r, lane);
         const int64_t sl = i * TRS + rr;
-        if (sl < a.dense_cap) my_dense[sl] = rr < n_ok ? make_key(acc[r], 0u) : 0ull;
+        if (sl < a.dense_cap)
+          my_dense[sl] = rr < n_ok ? make_key(acc[r], a.dense_ids ? (uint32_t)a.row_ids[p0 + t_row0 + rr] : 0u) : 0ull;
       }
       return;
     }
@@ -1112,17 +1119,18 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
     const int nprobe = h->nprobe < nlist ? h->nprobe : nlist;
     RIHIP_REQUIRE(nlist <= NLIST_MAX, RIHIP_ERR_SHAPE, "ip_index: nlist=%d > %d unsupported", nlist, NLIST_MAX);
     // one IVF pass over `n` queries: plan (tile split for this sampling step) -> list-major scan
+    const int target = 16 * RIHIP_NCU;  // wave work items aimed at: 2 waves per SIMD on every CU, twice over
     auto ivf_scan = [&](const float* Qp, int64_t n, const float* thr, uint64_t* cand, int64_t cap, int tile_step,
-                        int64_t dense_cap) -> int {
-      const int target = 16 * RIHIP_NCU;  // wave work items aimed at: 2 waves per SIMD on every CU, twice over
-      hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(256), 0, st, h->list_cnt.p, h->list_poff, nlist, tile_step, target,
-                         h->list_qoff.p, h->list_cur.p, h->work_off.p, h->plan.p, h->count.p, n * CSTRIDE);
+                        int64_t dense_cap, bool planned, int dense_ids) -> int {
+      if (!planned)   // (ivf_prepare already planned for the first scan that follows it)
+        hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(256), 0, st, h->list_cnt.p, h->list_poff, nlist, tile_step, target,
+                           h->list_qoff.p, h->list_cur.p, h->work_off.p, h->plan.p, h->count.p, n * CSTRIDE);
       LmArgs x;
       memset(&x, 0, sizeof(x));
       x.X = h->X; x.Q = Qp; x.thr = thr; x.cand = cand; x.cap = cap; x.count = h->count.p; x.row_ids = h->row_ids;
       x.list_poff = h->list_poff; x.list_len = h->list_len_dev; x.list_qoff = h->list_qoff.p; x.list_q = h->list_q.p;
       x.work_off = h->work_off.p; x.plan = h->plan.p; x.nlist = nlist; x.tile_step = tile_step; x.nprobe = nprobe;
-      x.dense_cap = dense_cap; x.count_stride = CSTRIDE;
+      x.dense_cap = dense_cap; x.count_stride = CSTRIDE; x.dense_ids = dense_ids;
       // n_work <= sum over (list, group) of (tiles/tpi + 1) <= target + #(list, query group) pairs
       const int64_t bound = (int64_t)target + nlist + (n * nprobe + 31) / 32 + 4;
       const dim3 grid((unsigned)((bound + 3) / 4));
@@ -1132,7 +1140,7 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
       return check_launch("ivf scan");
     };
     // coarse quantizer -> probed lists -> (query, list) pairs grouped by list
-    auto ivf_prepare = [&](const float* Qp, int64_t n) -> int {
+    auto ivf_prepare = [&](const float* Qp, int64_t n, int first_tile_step) -> int {
       RCCHK(h->coarse.reserve(n * nlist));
       RCCHK(h->probe_list.reserve(n * nprobe));
       RCCHK(h->list_q.reserve(n * nprobe));
@@ -1145,27 +1153,46 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
       else hipLaunchKernelGGL((ivf_coarse_kernel<128>), cg, dim3(256), 0, st, Qp, n, h->C, nlist, h->coarse.p);
       hipLaunchKernelGGL(ivf_select_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), sizeof(float) * 4 * nlist, st,
                          h->coarse.p, n, nlist, nprobe, h->probe_list.p, h->list_cnt.p);
-      // slot offsets (the scan's own plan launch recomputes them together with its tile split)
-      hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(256), 0, st, h->list_cnt.p, h->list_poff, nlist, 1, 1,
-                         h->list_qoff.p, h->list_cur.p, h->work_off.p, h->plan.p, h->count.p, (int64_t)0);
+      // slot offsets + the work split of the first scan (tile step `first_tile_step`) + zeroed candidate counters
+      hipLaunchKernelGGL(ivf_plan_kernel, dim3(1), dim3(256), 0, st, h->list_cnt.p, h->list_poff, nlist, first_tile_step, target,
+                         h->list_qoff.p, h->list_cur.p, h->work_off.p, h->plan.p, h->count.p, n * CSTRIDE);
       hipLaunchKernelGGL(ivf_scatter_kernel, dim3((unsigned)((n * nprobe + 255) / 256)), dim3(256), 0, st, h->probe_list.p,
                          n * nprobe, nprobe, h->list_cur.p, h->list_q.p);
       return check_launch("ivf prepare");
     };
-    // unfiltered pass (every probed vector is a candidate): small populations and the exact fallback
+    // unfiltered pass (every probed vector is a candidate): small populations, small batches and the exact fallback.
+    // Every (query, probed list) pair owns a dense slot range (slot = row inside the list): no atomics, 7 launches.
+    int64_t max_tiles = 0;
+    for (int c = 0; c < nlist; ++c) max_tiles = std::max<int64_t>(max_tiles, (h->list_len[c] + TR - 1) / TR * (TR / TRS));
+    const int64_t cap_lf = std::max<int64_t>(max_tiles * TRS, TRS);   // slots per (query, probe): the longest list
+    const int64_t cap_df = cap_lf * nprobe;
     auto ivf_full = [&](const float* Qp, int64_t n, const int* out_slot) -> int {
-      RCCHK(h->fcand.reserve(n * cap_full));
-      RCCHK(ivf_prepare(Qp, n));
-      RCCHK(ivf_scan(Qp, n, nullptr, h->fcand.p, cap_full, 1, 0));
+      RCCHK(h->fcand.reserve(n * cap_df));
+      HIPCHK(hipMemsetAsync(h->fcand.p, 0, sizeof(uint64_t) * (size_t)(n * cap_df), st));   // key 0 = below every score
+      RCCHK(ivf_prepare(Qp, n, 1));
+      RCCHK(ivf_scan(Qp, n, nullptr, h->fcand.p, cap_df, 1, cap_lf, true, 1));
+      // two-level select: the k best keys of every (query, probe) pair (one workgroup per pair), then the k best of a
+      // query's nprobe * k survivors -- a single workgroup over all ~100k slots of a query took 150 us
+      const int64_t np_ = n * nprobe;
+      RCCHK(h->count.reserve(std::max<int64_t>(np_, nq * CSTRIDE)));
+      RCCHK(h->scand.reserve(np_ * k));
+      hipLaunchKernelGGL(fill_int_kernel, dim3((unsigned)((np_ + 255) / 256)), dim3(256), 0, st, h->count.p, np_, (int)cap_lf);
+      FinArgs f1;
+      memset(&f1, 0, sizeof(f1));
+      f1.nq = np_; f1.k = k; f1.count = h->count.p; f1.cand = h->fcand.p; f1.cap = cap_lf; f1.mode = 0; f1.out_keys = h->scand.p;
+      RCCHK(launch_finalize(f1, (unsigned)np_, st));
+      hipLaunchKernelGGL(fill_int_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->count.p, n, (int)(nprobe * k));
       FinArgs f2;
       memset(&f2, 0, sizeof(f2));
-      f2.nq = n; f2.k = k; f2.count = h->count.p; f2.out_scores = out_s; f2.out_rows = out_r; f2.cand = h->fcand.p;
-      f2.cap = cap_full; f2.mode = 0; f2.out_slot = out_slot; f2.count_stride = CSTRIDE;
+      f2.nq = n; f2.k = k; f2.count = h->count.p; f2.out_scores = out_s; f2.out_rows = out_r; f2.cand = h->scand.p;
+      f2.cap = (int64_t)nprobe * k; f2.mode = 0; f2.out_slot = out_slot;
       RCCHK(launch_finalize(f2, (unsigned)n, st));
       return check_launch("finalize");
     };
     const int SS = 16;  // threshold sample: every 16th probed tile
-    if (cap_full <= 16384 || (double)k * 4.0 > (double)cap_full / SS) return ivf_full(Q, nq, nullptr);
+    // small populations or small batches (single requests): the unfiltered pass needs no threshold sample, no
+    // exactness check and no host sync
+    if (cap_full <= 16384 || (double)k * 4.0 > (double)cap_full / SS || nq * cap_df <= (int64_t)(1 << 23)) return ivf_full(Q, nq, nullptr);
 
     const double m = (double)k / SS;
     const int rank = (int)ceil(m + 4.0 * sqrt(m) + 4.0);
@@ -1173,19 +1200,17 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
     while ((double)cap < 2.5 * rank * SS) cap <<= 1;
     if (cap > cap_full) cap = cap_full;
     // pass A: every SS-th tile of each probed list, all of its scores kept in dense per-(query, probe) slots
-    int64_t max_tiles = 0;
-    for (int c = 0; c < nlist; ++c) max_tiles = std::max<int64_t>(max_tiles, (h->list_len[c] + TR - 1) / TR * (TR / TRS));
     const int64_t cap_l = (max_tiles + SS - 1) / SS * TRS;             // sampled rows of the longest list
     const int64_t cap_s = cap_l * nprobe;
     RCCHK(h->scand.reserve(nq * cap_s));
     RCCHK(h->cand.reserve(nq * cap));
-    RCCHK(ivf_prepare(Q, nq));
+    RCCHK(ivf_prepare(Q, nq, SS));
     HIPCHK(hipMemsetAsync(h->scand.p, 0, sizeof(uint64_t) * (size_t)(nq * cap_s), st));   // key 0 = below every score
-    RCCHK(ivf_scan(Q, nq, nullptr, h->scand.p, cap_s, SS, cap_l));
+    RCCHK(ivf_scan(Q, nq, nullptr, h->scand.p, cap_s, SS, cap_l, true, 0));
     hipLaunchKernelGGL(fill_int_kernel, dim3(nqb), dim3(256), 0, st, h->count.p, nq, (int)cap_s);
     fa.cand = h->scand.p; fa.cap = cap_s; fa.mode = 1; fa.rank = rank; fa.thr_out = h->thr.p;
     RCCHK(launch_finalize(fa, (unsigned)nq, st));
-    RCCHK(ivf_scan(Q, nq, h->thr.p, h->cand.p, cap, 1, 0));                         // pass B: all probed tiles, filtered
+    RCCHK(ivf_scan(Q, nq, h->thr.p, h->cand.p, cap, 1, 0, false, 0));                         // pass B: all probed tiles, filtered
     fa.cand = h->cand.p; fa.cap = cap; fa.mode = 0; fa.thr_out = nullptr; fa.fail_flags = h->fail_flags.p;
     fa.ivf_thr = h->thr.p; fa.count_stride = CSTRIDE;
     RCCHK(launch_finalize(fa, (unsigned)nq, st));

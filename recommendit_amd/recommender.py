@@ -170,13 +170,19 @@ class GpuRecommendationPipeline:
         k = k or self.top_k_results
         uid = torch.as_tensor(user_ids, dtype=torch.long, device=L.device())
         q = self.model.get_user_embeddings(uid, as_tensor=True)
-        rs, cand = self.index.batch_search_device(q, k=self.top_k_candidates, normalized=False)
+        # tower outputs are already L2-normalised (two_tower.py:42): the wrapper's re-normalisation (faiss_index.py:108-110)
+        # would divide by 1 +- 1e-7 and cost three tensor ops per request
+        rs, cand = self.index.batch_search_device(q, k=self.top_k_candidates, normalized=True)
         nq, kc = cand.shape
         X = build_ranking_features_device(self.store, uid, cand, self.ranker.feature_names)
-        scores = self.ranker.predict_device(X).view(nq, kc)
-        scores = torch.where(cand >= 0, scores, torch.full_like(scores, float("-inf")))
-        order = torch.sort(scores, dim=1, descending=True, stable=True).indices[:, :k]
-        return (torch.gather(cand, 1, order), torch.gather(scores, 1, order), torch.gather(rs, 1, order))
+        scores = self.ranker.predict_device(X)
+        k = min(k, kc)
+        ids = torch.empty((nq, k), dtype=torch.int64, device=cand.device)
+        top = torch.empty((nq, k), dtype=torch.float64, device=cand.device)
+        trs = torch.empty((nq, k), dtype=torch.float32, device=cand.device)
+        L.check(L.lib().rihip_rank_topk(scores.data_ptr(), cand.data_ptr(), rs.data_ptr(), nq, kc, k, ids.data_ptr(),
+                                        top.data_ptr(), trs.data_ptr(), L.stream_ptr()), "rank_topk")
+        return ids, top, trs
 
     def get_recommendations(self, user_id: int, k: Optional[int] = None) -> List[Dict[str, Any]]:
         ids, sc, rs = self.recommend_batch([user_id], k)
