@@ -437,13 +437,22 @@ def leg_serve(model, X, n_users_local, dev, cpu):
         pipe.recommend_batch(one)
         torch.cuda.synchronize(); lat.append((time.perf_counter() - t0) * 1e3)
     lat.sort()
+    one_list = one.tolist()
+    pipe.recommend_batch(one_list, graph=True)          # capture
+    latg = []
+    for _ in range(50):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        pipe.recommend_batch(one_list, graph=True)
+        torch.cuda.synchronize(); latg.append((time.perf_counter() - t0) * 1e3)
+    latg.sort()
     rps = nqs * 6 / dts
     # ranker alone on the candidates of one batch: node visits / s (neither HBM nor MFMA bound: dependent LDS reads)
     Xf = torch.rand((nqs * K_TOP, 50), device=dev, generator=gg)
     ranker.predict_device(Xf)
     dtr = timed(lambda i: ranker.predict_device(Xf), 5, 1)
     out = {"metric": "end_to_end_recommendations_per_sec", "value": rps, "unit": "requests/s", "batch": nqs,
-           "single_request_ms_p50": lat[len(lat) // 2], "single_request_ms_max": lat[-1], "ivf_build_s": build_s,
+           "single_request_ms_p50": lat[len(lat) // 2], "single_request_ms_max": lat[-1],
+           "single_request_graph_ms_p50": latg[len(latg) // 2], "single_request_graph_ms_p99": latg[-1], "ivf_build_s": build_s,
            "pipeline": "user tower -> IVF-IP(100 lists, nprobe 10, 500 cands) -> feature assembly -> LambdaMART 500 "
                        "trees x 63 leaves x 50 features -> top-20",
            "ranker": {"candidates_per_s": nqs * K_TOP * 5 / dtr, "tree_walks_per_s": nqs * K_TOP * 5 / dtr * 500,
@@ -451,7 +460,8 @@ def leg_serve(model, X, n_users_local, dev, cpu):
                       "roofline": {"bound": "neither", "note": "forest (1 MB) is LDS-resident; chains of dependent LDS "
                                    "reads bound the walk (SURVEY §8d): HBM/MFMA fractions are not meaningful",
                                    "hbm_frac": nqs * K_TOP * 5 / dtr * 208 / PEAK_HBM_BYTES}}}
-    log(f"[bench] serve: {rps:,.0f} req/s batched, {lat[len(lat) // 2]:.2f} ms p50 single; ranker "
+    log(f"[bench] serve: {rps:,.0f} req/s batched, {lat[len(lat) // 2]:.2f} ms p50 single ({latg[len(latg) // 2]:.3f} ms as a "
+        f"hipGraph); ranker "
         f"{nqs * K_TOP * 5 / dtr / 1e6:.1f} M candidates/s")
     if cpu:
         from oracle import gbdt_np as G

@@ -161,14 +161,59 @@ class GpuRecommendationPipeline:
         """defaults = settings.TOP_K_CANDIDATES / TOP_K_RESULTS (src/config.py:11-12)"""
         self.model, self.index, self.ranker, self.store = model, index, ranker, store
         self.top_k_candidates, self.top_k_results = top_k_candidates, top_k_results
+        self._graphs: Dict[Tuple[int, int], Any] = {}
 
     @torch.no_grad()
-    def recommend_batch(self, user_ids, k: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    def recommend_batch(self, user_ids, k: Optional[int] = None, graph: bool = False
+                        ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """-> (item_ids i64 [nq,k], ranker scores f64 [nq,k], retrieval scores f32 [nq,k]) on device; -1 padded
         where retrieval returned fewer than k candidates.  Ties in the ranker score keep retrieval order
-        (DataFrame.nlargest(keep='first'), recommender.py:346)."""
+        (DataFrame.nlargest(keep='first'), recommender.py:346).
+
+        graph=True (small request batches): the ~20 launches of the chain are captured once per (batch size, k) into a
+        hipGraph and replayed -- a single request is launch-bound otherwise.  The returned tensors are the graph's static
+        outputs: valid until the next replay of the same shape.  Falls back to the eager chain when the shape takes a
+        path with a host synchronisation (large batches: the thresholded IVF scan checks exactness on the host)."""
         k = k or self.top_k_results
+        if graph:
+            out = self._replay(user_ids, k)
+            if out is not None:
+                return out
         uid = torch.as_tensor(user_ids, dtype=torch.long, device=L.device())
+        return self._chain(uid, k)
+
+    def _replay(self, user_ids, k: int):
+        nq = len(user_ids)
+        key = (nq, k)
+        ent = self._graphs.get(key)
+        if ent is None:
+            dev = L.device()
+            su = torch.ones((nq,), dtype=torch.long, device=dev)
+            try:
+                cur = torch.cuda.current_stream(dev)
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):      # warm-up: scratch buffers, LDS grants, lazy module loads
+                    for _ in range(2):
+                        self._chain(su, k)
+                cur.wait_stream(side)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    out = self._chain(su, k)
+                ent = (g, su, out)
+            except Exception:                        # a path with a host sync cannot be captured: stay eager for this shape
+                torch.cuda.synchronize()
+                ent = False
+            self._graphs[key] = ent
+        if ent is False:
+            return None
+        g, su, out = ent
+        su.copy_(torch.as_tensor(user_ids, dtype=torch.long), non_blocking=True)
+        g.replay()
+        return out
+
+    def _chain(self, uid: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         q = self.model.get_user_embeddings(uid, as_tensor=True)
         # tower outputs are already L2-normalised (two_tower.py:42): the wrapper's re-normalisation (faiss_index.py:108-110)
         # would divide by 1 +- 1e-7 and cost three tensor ops per request
@@ -184,8 +229,8 @@ class GpuRecommendationPipeline:
                                         top.data_ptr(), trs.data_ptr(), L.stream_ptr()), "rank_topk")
         return ids, top, trs
 
-    def get_recommendations(self, user_id: int, k: Optional[int] = None) -> List[Dict[str, Any]]:
-        ids, sc, rs = self.recommend_batch([user_id], k)
+    def get_recommendations(self, user_id: int, k: Optional[int] = None, graph: bool = False) -> List[Dict[str, Any]]:
+        ids, sc, rs = self.recommend_batch([user_id], k, graph=graph)
         out = []
         for rank, (i, s, r) in enumerate(zip(ids[0].tolist(), sc[0].tolist(), rs[0].tolist()), start=1):
             if i >= 0:

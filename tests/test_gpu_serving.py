@@ -97,6 +97,11 @@ def test_batched_pipeline_matches_stagewise_oracle(tmp_path, kind, lists):
             assert np.allclose(np.sort(sc[qi]), np.sort(s[order]), atol=1e-12)
     one = pipe.get_recommendations(7, k=5)
     assert [r["item_id"] for r in one] == ids[1][:5].tolist() and one[0]["rank"] == 1
+    # the same chain replayed as a hipGraph (single requests are launch-bound)
+    for u in (7, 300, 7):
+        g = pipe.get_recommendations(u, k=5, graph=True)
+        e = pipe.get_recommendations(u, k=5)
+        assert g == e
 
 
 def test_batched_run_evaluate_equals_per_user_protocol(tmp_path):
