@@ -143,8 +143,14 @@ def build_ranking_features_device(store: GpuFeatureStore, user_ids: torch.Tensor
     """X f32 [nq*kc, len(feature_names)] on device (the matrix ranker.predict would see)."""
     lib = L.lib()
     ut, it = store.device_tables()
-    canon = {n: i for i, n in enumerate(feature_columns())}
-    col_map = torch.tensor([canon.get(n, -1) for n in feature_names], dtype=torch.int32, device=ut.device)
+    key = tuple(feature_names)
+    col_map = store._col_maps.get(key) if hasattr(store, "_col_maps") else None
+    if col_map is None or col_map.device != ut.device:   # one H2D copy per feature list, not per request
+        canon = {n: i for i, n in enumerate(feature_columns())}
+        col_map = torch.tensor([canon.get(n, -1) for n in feature_names], dtype=torch.int32, device=ut.device)
+        if not hasattr(store, "_col_maps"):
+            store._col_maps = {}
+        store._col_maps[key] = col_map
     uid = L.i64c(user_ids)
     cand = L.i64c(cand_ids)
     nq, kc = cand.shape
