@@ -72,6 +72,13 @@ int rihip_tower_backward(const float* table, int64_t n_rows, const int64_t* ids,
                          const float* out, const float* denom, const float* hid, float dropout_scale, float* dX,
                          float* dW1, float* db1, float* dW2, float* db2, int accumulate, float* workspace,
                          void* stream);
+/* Same, plus dx_event (a hipEvent_t, nullable): recorded on `stream` as soon as dX is complete -- before the
+ * weight-gradient kernels -- so a caller can start the embedding-row gradient reduction on another stream beside them. */
+int rihip_tower_backward_ev(const float* table, int64_t n_rows, const int64_t* ids, const float* genres, int64_t B,
+                            int d, int hidden, const float* W1, const float* W2, const float* grad_out,
+                            const float* out, const float* denom, const float* hid, float dropout_scale, float* dX,
+                            float* dW1, float* db1, float* dW2, float* db2, int accumulate, float* workspace,
+                            void* stream, void* dx_event);
 
 /* nn.Embedding backward (dense): grad_table[ids[b]] += dX[b]; row 0 (padding_idx, two_tower.py:27,54) skipped */
 int rihip_embedding_scatter_add(float* grad_table, int64_t n_rows, const int64_t* ids, const float* dX, int64_t B,

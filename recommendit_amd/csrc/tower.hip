@@ -571,11 +571,11 @@ extern "C" int64_t rihip_tower_backward_workspace_floats(int64_t B, int d, int h
   return ((grid > 0 ? grid : 1) + SLAB_GROUPS) * P + B * (int64_t)(d + hidden);
 }
 
-extern "C" int rihip_tower_backward(const float* table, int64_t n_rows, const int64_t* ids, const float* genres,
-                                    int64_t B, int d, int hidden, const float* W1, const float* W2,
-                                    const float* grad_out, const float* out, const float* denom, const float* hid,
-                                    float dropout_scale, float* dX, float* dW1, float* db1, float* dW2, float* db2,
-                                    int accumulate, float* workspace, void* stream) {
+extern "C" int rihip_tower_backward_ev(const float* table, int64_t n_rows, const int64_t* ids, const float* genres,
+                                       int64_t B, int d, int hidden, const float* W1, const float* W2,
+                                       const float* grad_out, const float* out, const float* denom, const float* hid,
+                                       float dropout_scale, float* dX, float* dW1, float* db1, float* dW2, float* db2,
+                                       int accumulate, float* workspace, void* stream, void* dx_event) {
   RIHIP_REQUIRE(rihip_tower_supported(d, hidden), RIHIP_ERR_SHAPE,
                 "tower_backward: unsupported (embed_dim=%d, hidden_dim=%d)", d, hidden);
   if (B <= 0) return RIHIP_OK;
@@ -603,11 +603,12 @@ extern "C" int rihip_tower_backward(const float* table, int64_t n_rows, const in
     const char* ev = getenv("RIHIP_TOWER_BWD");
     const int which = ev ? atoi(ev) : 2;
     if (((which == 2 && B >= 49152) || which == 3) && aligned16(W2) && aligned16(dX))
-      nslab = rihip_launch_tower_bwd2(d, hidden, item, a, act, st);
+      nslab = rihip_launch_tower_bwd2(d, hidden, item, a, act, st, (hipEvent_t)dx_event);
   }
   if (nslab == 0) {
     DISPATCH_DH(launch_bwd, item, a, grid, st)
     nslab = grid;
+    if (dx_event) (void)hipEventRecord((hipEvent_t)dx_event, st);
   }
   RIHIP_CHECK_LAUNCH();
   const int G = nslab < SLAB_GROUPS ? nslab : SLAB_GROUPS;
@@ -619,6 +620,15 @@ extern "C" int rihip_tower_backward(const float* table, int64_t n_rows, const in
                      dW2, db2, accumulate);
   RIHIP_CHECK_LAUNCH();
   return RIHIP_OK;
+}
+
+extern "C" int rihip_tower_backward(const float* table, int64_t n_rows, const int64_t* ids, const float* genres,
+                                    int64_t B, int d, int hidden, const float* W1, const float* W2,
+                                    const float* grad_out, const float* out, const float* denom, const float* hid,
+                                    float dropout_scale, float* dX, float* dW1, float* db1, float* dW2, float* db2,
+                                    int accumulate, float* workspace, void* stream) {
+  return rihip_tower_backward_ev(table, n_rows, ids, genres, B, d, hidden, W1, W2, grad_out, out, denom, hid, dropout_scale,
+                                 dX, dW1, db1, dW2, db2, accumulate, workspace, stream, nullptr);
 }
 
 extern "C" int rihip_embedding_scatter_add(float* grad_table, int64_t n_rows, const int64_t* ids, const float* dX,

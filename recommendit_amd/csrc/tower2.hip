@@ -553,7 +553,7 @@ __global__ __launch_bounds__(512, 2) void tower_wgrad_kernel(TowerBwdArgs a, con
 }
 
 template <int D, int H, bool ITEM>
-int launch_bwd2(const TowerBwdArgs& a, float* act, hipStream_t st) {
+int launch_bwd2(const TowerBwdArgs& a, float* act, hipStream_t st, hipEvent_t dx_event) {
   constexpr int K1 = D + (ITEM ? 18 : 0);
   constexpr int XW = ((K1 + 31) / 32) * 32;
   float* gy = act;
@@ -566,6 +566,7 @@ int launch_bwd2(const TowerBwdArgs& a, float* act, hipStream_t st) {
     const int64_t nchunks = (a.B + 255) / 256;
     const int grid = (int)(nchunks < RIHIP_NCU ? nchunks : RIHIP_NCU);
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a, gy, dpre, K1);
+    if (dx_event) (void)hipEventRecord(dx_event, st);   // dX is complete: the row-gradient reduce may start beside the weight gradients
   }
   auto k = tower_wgrad_kernel<D, H, ITEM>;
   const size_t lds = 2 * (size_t)32 * (D + H + H + XW) * sizeof(float);
@@ -579,8 +580,10 @@ int launch_bwd2(const TowerBwdArgs& a, float* act, hipStream_t st) {
 
 }  // namespace
 
-int rihip_launch_tower_bwd2(int d, int hidden, bool item, const TowerBwdArgs& a, float* act, hipStream_t st) {
-  if (d == 128 && hidden == 128) return item ? launch_bwd2<128, 128, true>(a, act, st) : launch_bwd2<128, 128, false>(a, act, st);
+int rihip_launch_tower_bwd2(int d, int hidden, bool item, const TowerBwdArgs& a, float* act, hipStream_t st,
+                            hipEvent_t dx_event) {
+  if (d == 128 && hidden == 128)
+    return item ? launch_bwd2<128, 128, true>(a, act, st, dx_event) : launch_bwd2<128, 128, false>(a, act, st, dx_event);
   return 0;
 }
 

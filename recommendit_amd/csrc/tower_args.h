@@ -41,7 +41,9 @@ struct TowerBwdArgs {
 // two-kernel backward (tower2.hip): data-gradient kernel (wave per 32 rows, weights in LDS) that also writes gy [B,D]
 // and dPre [B,H] to `act`, then the weight-gradient kernel (LDS-tiled split-K over the batch) that fills the slabs.
 // Returns the number of slabs written (0: no instantiation for this (d, hidden)).
-int rihip_launch_tower_bwd2(int d, int hidden, bool item, const TowerBwdArgs& a, float* act, hipStream_t st);
+// dx_event (nullable) is recorded on st as soon as dX is complete (before the weight-gradient kernel).
+int rihip_launch_tower_bwd2(int d, int hidden, bool item, const TowerBwdArgs& a, float* act, hipStream_t st,
+                            hipEvent_t dx_event);
 
 // wave-per-32-rows forward (tower2.hip); returns false when the (d, hidden) pair has no instantiation
 bool rihip_launch_tower_fwd2(int d, int hidden, bool item, const TowerFwdArgs& a, hipStream_t st);

@@ -136,6 +136,7 @@ class HipBPRTrainer:
         self._dI_work = None
         self._side_stream = torch.cuda.Stream(device=self.dev)
         self._side_stream2 = torch.cuda.Stream(device=self.dev)
+        self._ev_dxu, self._ev_dxi = torch.cuda.Event(), torch.cuda.Event()   # "dX complete" of the two tower backwards
         self._eager_steps = 0  # bench hook: list collecting (start, end) events around every sweep launch
         self.pg = process_group
         self.dist = bool(distributed) or process_group is not None   # collectives are issued iff this is set
@@ -267,15 +268,22 @@ class HipBPRTrainer:
                                              (self.fws_u if genres is None else self.fws_i).data_ptr(),
                                              self.step_dev.data_ptr(), self._st), "tower_forward")
 
-    def _bwd(self, table, ids, genres, keys, gout, out, den, hid, dX):
+    def _bwd(self, table, ids, genres, keys, gout, out, den, hid, dX, dx_event=None):
+        """dx_event: a torch.cuda.Event that is recorded on the launch stream as soon as dX is complete (before the
+        weight-gradient kernels)."""
         scale = 1.0 / (1.0 - self.p_drop) if (self.model.training and self.p_drop > 0) else 1.0
-        L.check(self.lib.rihip_tower_backward(table.data_ptr(), table.shape[0], ids.data_ptr(), L.ptr(genres),
+        ev = 0
+        if dx_event is not None:
+            if not dx_event.cuda_event:      # the handle only exists after a first record
+                dx_event.record(torch.cuda.current_stream(self.dev))
+            ev = dx_event.cuda_event
+        L.check(self.lib.rihip_tower_backward_ev(table.data_ptr(), table.shape[0], ids.data_ptr(), L.ptr(genres),
                                               ids.numel(), self.d, self.H, self.pv[keys[0]].data_ptr(),
                                               self.pv[keys[2]].data_ptr(), gout.data_ptr(), out.data_ptr(),
                                               den.data_ptr(), hid.data_ptr(), scale, dX.data_ptr(),
                                               self.gv[keys[0]].data_ptr(), self.gv[keys[1]].data_ptr(),
                                               self.gv[keys[2]].data_ptr(), self.gv[keys[3]].data_ptr(), 0,
-                                              self.bws.data_ptr(), self._st), "tower_backward")
+                                              self.bws.data_ptr(), self._st, ev), "tower_backward")
 
     def step(self, user_ids: torch.Tensor, item_ids: torch.Tensor, item_genres: torch.Tensor,
              lr: Optional[float] = None) -> torch.Tensor:
@@ -372,18 +380,24 @@ class HipBPRTrainer:
 
         early_group_user()
         # user tower first: in the multi-GPU stored-G form dI is still being reduce-scattered
-        self._bwd(self.utab, user_ids, None, ukeys, self.dU, self.U, self.denU, self.hidU, self.dXu)
+        self._bwd(self.utab, user_ids, None, ukeys, self.dU, self.U, self.denU, self.hidU, self.dXu,
+                  dx_event=self._ev_dxu if sparse else None)
         pp = self.part.data_ptr()
         o1 = self.np_mlp
         o2 = o1 + self.np_rows
-        if sparse:   # the user rows' segment sums run beside the item tower's backward
-            sideA.wait_stream(cur)
+        if sparse:   # the user rows' segment sums start as soon as dXu exists: beside the user tower's weight gradients
+            sideA.wait_event(self._ev_dxu)
             with torch.cuda.stream(sideA):
                 self.uopt.reduce(self.dXu, pp + 8 * o1, sideA.cuda_stream)
         early_group_item()
         if self._dI_work is not None:
             self._dI_work.wait(); self._dI_work = None
-        self._bwd(itab, iids, item_genres, ikeys, self.dI, self.I, self.denI, self.hidI, self.dXi)
+        self._bwd(itab, iids, item_genres, ikeys, self.dI, self.I, self.denI, self.hidI, self.dXi,
+                  dx_event=self._ev_dxi if early_item_group else None)
+        if early_item_group:   # ... and the item rows' beside the item tower's weight gradients
+            sideB.wait_event(self._ev_dxi)
+            with torch.cuda.stream(sideB):
+                self.iopt.reduce(self.dXi, pp + 8 * o2, sideB.cuda_stream)
 
         # ---- gradient exchange (multi-GPU) + global grad norm -> clip coef (device scalar)
         iid, dXi = item_ids, self.dXi
@@ -414,7 +428,6 @@ class HipBPRTrainer:
             if iid.numel() > 0:
                 if early_item_group:
                     cur.wait_stream(sideB)
-                    self.iopt.reduce(dXi, pp + 8 * o2, st)
                 else:
                     self.iopt.group_reduce(iid, dXi, pp + 8 * o2, st)
             else:   # this rank owns none of the rows of the step

@@ -20,8 +20,11 @@ for _ in range(3):
     tr.step(u, it, gen)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+import time
 e0.record()
+h0 = time.perf_counter()
 for _ in range(20):
     tr.step(u, it, gen)
+h1 = time.perf_counter()
 e1.record(); torch.cuda.synchronize()
-print(f"B={B} graph={USE_GRAPH}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us/step")
+print(f"B={B} graph={USE_GRAPH}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us/step (host enqueue {(h1 - h0) / 20 * 1e6:.1f} us/step)")
