@@ -80,9 +80,15 @@ int rihip_tower_backward_ev(const float* table, int64_t n_rows, const int64_t* i
                             float* dW1, float* db1, float* dW2, float* db2, int accumulate, float* workspace,
                             void* stream, void* dx_event);
 
-/* nn.Embedding backward (dense): grad_table[ids[b]] += dX[b]; row 0 (padding_idx, two_tower.py:27,54) skipped */
+/* nn.Embedding backward (dense): grad_table[ids[b]] += dX[b]; row 0 (padding_idx, two_tower.py:27,54) and ids outside
+ * [1, n_rows) are skipped.  Bitwise reproducible: every row receives its samples one after the other in batch order,
+ * starting from its current contents (the float32 chain of index_add_ on a CPU) -- no floating-point atomics.
+ * _add2 handles two tables (user + item) in one launch. */
 int rihip_embedding_scatter_add(float* grad_table, int64_t n_rows, const int64_t* ids, const float* dX, int64_t B,
                                 int d, void* stream);
+int rihip_embedding_scatter_add2(float* grad_a, int64_t n_rows_a, const int64_t* ids_a, const float* dX_a, int64_t B_a,
+                                 float* grad_b, int64_t n_rows_b, const int64_t* ids_b, const float* dX_b,
+                                 int64_t B_b, int d, void* stream);
 
 /* ---- losses --------------------------------------------------------------------------------
  * rihip_bpr_pair_loss replaces TwoTowerModel.bpr_loss (two_tower.py:117-130) and its backward:

@@ -37,6 +37,7 @@ SIGNATURES = {
     "rihip_tower_backward_ev": (C.c_int, [vp, c_i64, vp, vp, c_i64, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_float,
                                           vp, vp, vp, vp, vp, C.c_int, vp, vp, vp]),
     "rihip_embedding_scatter_add": (C.c_int, [vp, c_i64, vp, vp, c_i64, C.c_int, vp]),
+    "rihip_embedding_scatter_add2": (C.c_int, [vp, c_i64, vp, vp, c_i64, vp, c_i64, vp, vp, c_i64, C.c_int, vp]),
     "rihip_bpr_pair_loss": (C.c_int, [vp, vp, vp, c_i64, C.c_int, vp, vp, vp, vp, vp, vp]),
     "rihip_rowdot": (C.c_int, [vp, vp, c_i64, c_i64, C.c_int, vp, vp]),
     "rihip_inbatch_workspace_doubles": (c_i64, [c_i64]),

@@ -461,16 +461,118 @@ __global__ void slab_reduce2_kernel(const float* __restrict__ part, int G, int P
 }
 constexpr int SLAB_GROUPS = 16;
 
-// dense embedding grad: grad[ids[b]] += dX[b]  (padding row 0 gets no gradient)
-__global__ void scatter_add_rows_kernel(float* __restrict__ grad, int64_t n_rows, const int64_t* __restrict__ ids,
-                                        const float* __restrict__ dX, int64_t B, int D) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * D) return;
-  const int64_t b = i / D;
-  const int c = (int)(i % D);
-  const int64_t id = ids[b];
-  if (id <= 0 || id >= n_rows) return;
-  atomicAdd(&grad[id * D + c], dX[i]);
+// ---- dense embedding grad: grad[ids[b]] += dX[b]  (padding row 0 gets no gradient), bitwise reproducible.
+// Workgroup w of a table owns the row range [1 + w*R, 1 + (w+1)*R): it walks the batch in chunks of 16384 positions,
+// compacts the positions whose id falls in its range (in batch order), sorts the (row, position) keys in LDS and lets ONE
+// lane group add every run of equal rows to the table row, sample after sample in batch order, starting from the row's
+// current contents -- the float32 chain of index_add_ / np.add.at on a CPU.  No floating-point atomics.
+constexpr int SCAT_CHUNK = 16384;     // batch positions per pass (14 bits of the key)
+constexpr int SCAT_RBITS = 18;        // rows per workgroup <= 2^18 (18 bits of the key)
+struct ScatterDesc {
+  float* grad; int64_t n_rows; const int64_t* ids; const float* dX; int64_t B;
+};
+struct ScatterArgs { ScatterDesc t[2]; int D; int64_t rows_per_wg[2]; };
+
+template <int LPR>   // lanes per row (float4 each); 0 = generic width, one lane per row looping over the columns
+__global__ __launch_bounds__(1024) void scatter_range_kernel(ScatterArgs a) {
+  extern __shared__ uint32_t skeys[];
+  __shared__ int wave_cnt[2][16];
+  const ScatterDesc& t = a.t[blockIdx.y];
+  const int64_t R = a.rows_per_wg[blockIdx.y];
+  const int64_t lo = 1 + (int64_t)blockIdx.x * R;
+  int64_t hi = lo + R;
+  if (hi > t.n_rows) hi = t.n_rows;
+  if (lo >= hi) return;   // workgroup-uniform
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int64_t c0 = 0; c0 < t.B; c0 += SCAT_CHUNK) {
+    const int n = (int)((t.B - c0 < SCAT_CHUNK) ? t.B - c0 : SCAT_CHUNK);
+    // ---- stable compaction of the chunk's positions that hit [lo, hi); all id loads of the pass are in flight together
+    int64_t idv[SCAT_CHUNK / 1024];
+#pragma unroll
+    for (int it = 0; it < SCAT_CHUNK / 1024; ++it) {
+      const int i = it * 1024 + tid;
+      idv[it] = (i < n) ? t.ids[c0 + i] : 0;
+    }
+    int m = 0;
+#pragma unroll
+    for (int it = 0; it < SCAT_CHUNK / 1024; ++it) {
+      if (it * 1024 >= n) break;   // uniform
+      const int64_t id = idv[it];
+      const bool in = id >= lo && id < hi;
+      const uint64_t bal = __ballot(in);
+      if (lane == 0) wave_cnt[it & 1][w] = __popcll(bal);
+      __syncthreads();
+      int before = 0, total = 0;
+#pragma unroll
+      for (int x = 0; x < 16; ++x) {
+        const int c = wave_cnt[it & 1][x];
+        before += (x < w) ? c : 0;
+        total += c;
+      }
+      if (in)
+        skeys[m + before + __popcll(bal & ((1ull << lane) - 1ull))] = ((uint32_t)(id - lo) << 14) | (uint32_t)(it * 1024 + tid);
+      m += total;
+    }
+    if (m == 0) { __syncthreads(); continue; }   // uniform
+    int np2 = 2;
+    while (np2 < m) np2 <<= 1;
+    for (int i = m + tid; i < np2; i += 1024) skeys[i] = 0xFFFFFFFFu;
+    // ---- bitonic sort of the keys (unique: the position is part of the key).  Exchanges at distance <= 64 stay inside
+    // the 128-key segment owned by one wave (LDS operations of a wave execute in order): only the passes that reach
+    // across segments, and the first pass after one, need the workgroup barrier.
+    int prev_j = 128;
+    for (int k = 2; k <= np2; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        if (j >= 128 || prev_j >= 128) __syncthreads();
+        else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        prev_j = j;
+        for (int x = tid; x < (np2 >> 1); x += 1024) {
+          const int l = ((x & ~(j - 1)) << 1) | (x & (j - 1));
+          const int h = l | j;
+          const uint32_t u = skeys[l], v = skeys[h];
+          const bool up = (l & k) == 0;
+          if ((u > v) == up) { skeys[l] = v; skeys[h] = u; }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- runs of equal rows: sequential float32 chain onto the table row
+    const float* base = t.dX + (size_t)c0 * a.D;
+    if (LPR > 0) {
+      constexpr int D = LPR * 4, GPB = 1024 / (LPR > 0 ? LPR : 1);
+      const int g = tid / (LPR > 0 ? LPR : 1), c4 = tid % (LPR > 0 ? LPR : 1);
+      for (int i = g; i < m; i += GPB) {
+        const uint32_t key = skeys[i];
+        const uint32_t rid = key >> 14;
+        if (i > 0 && (skeys[i - 1] >> 14) == rid) continue;   // not the head of a run
+        f32x4* dst = reinterpret_cast<f32x4*>(t.grad + (size_t)(lo + rid) * D) + c4;
+        f32x4 acc = *dst;
+        for (int j = i; j < m; ++j) {
+          const uint32_t kj = skeys[j];
+          if ((kj >> 14) != rid) break;
+          const f32x4 v = reinterpret_cast<const f32x4*>(base + (size_t)(kj & 16383u) * D)[c4];
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        *dst = acc;
+      }
+    } else {
+      const int D = a.D;
+      for (int e = tid; e < m * D; e += 1024) {
+        const int i = e / D, c = e % D;
+        const uint32_t rid = skeys[i] >> 14;
+        if (i > 0 && (skeys[i - 1] >> 14) == rid) continue;
+        float* dst = t.grad + (size_t)(lo + rid) * D + c;
+        float acc = *dst;
+        for (int j = i; j < m; ++j) {
+          const uint32_t kj = skeys[j];
+          if ((kj >> 14) != rid) break;
+          acc += base[(size_t)(kj & 16383u) * D + c];
+        }
+        *dst = acc;
+      }
+    }
+    __syncthreads();   // the next chunk's keys overwrite skeys; its row updates follow this chunk's (same workgroup)
+  }
 }
 
 template <int D, int H>
@@ -631,13 +733,67 @@ extern "C" int rihip_tower_backward(const float* table, int64_t n_rows, const in
                                  dX, dW1, db1, dW2, db2, accumulate, workspace, stream, nullptr);
 }
 
-extern "C" int rihip_embedding_scatter_add(float* grad_table, int64_t n_rows, const int64_t* ids, const float* dX,
-                                           int64_t B, int d, void* stream) {
-  RIHIP_REQUIRE(grad_table && ids && dX, RIHIP_ERR_ARG, "embedding_scatter_add: null pointer");
-  if (B <= 0) return RIHIP_OK;
-  const int64_t n = B * d;
-  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     grad_table, n_rows, ids, dX, B, d);
+namespace {
+int scatter_launch(ScatterArgs a, int n_tables, hipStream_t st) {
+  int64_t maxB = 0;
+  int nwg = 4;
+  bool al = a.D == 32 || a.D == 64 || a.D == 128;
+  for (int t = 0; t < n_tables; ++t) {
+    maxB = a.t[t].B > maxB ? a.t[t].B : maxB;
+    al = al && aligned16(a.t[t].grad) && aligned16(a.t[t].dX);
+  }
+  // workgroups per table: ~128 batch positions each, and at most 2^18 rows each (the key holds 18 row bits)
+  int64_t want = maxB / 128;
+  want = want < 4 ? 4 : (want > 64 ? 64 : want);
+  for (int t = 0; t < n_tables; ++t) {
+    const int64_t need = ((a.t[t].n_rows >> SCAT_RBITS) + 1);
+    want = need > want ? need : want;
+  }
+  nwg = (int)want;
+  for (int t = 0; t < n_tables; ++t) a.rows_per_wg[t] = (a.t[t].n_rows - 1 + nwg - 1) / nwg > 0 ? (a.t[t].n_rows - 1 + nwg - 1) / nwg : 1;
+  int np2 = 64;
+  const int64_t cap = maxB < SCAT_CHUNK ? maxB : SCAT_CHUNK;
+  while (np2 < cap) np2 <<= 1;
+  const size_t lds = (size_t)np2 * 4;
+  const dim3 grid((unsigned)nwg, (unsigned)n_tables);
+  static bool granted = false;
+  if (!granted) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scatter_range_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, SCAT_CHUNK * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scatter_range_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, SCAT_CHUNK * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scatter_range_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, SCAT_CHUNK * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scatter_range_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, SCAT_CHUNK * 4);
+    granted = true;
+  }
+  if (al && a.D == 128) hipLaunchKernelGGL((scatter_range_kernel<32>), grid, dim3(1024), lds, st, a);
+  else if (al && a.D == 64) hipLaunchKernelGGL((scatter_range_kernel<16>), grid, dim3(1024), lds, st, a);
+  else if (al && a.D == 32) hipLaunchKernelGGL((scatter_range_kernel<8>), grid, dim3(1024), lds, st, a);
+  else hipLaunchKernelGGL((scatter_range_kernel<0>), grid, dim3(1024), lds, st, a);
   RIHIP_CHECK_LAUNCH();
   return RIHIP_OK;
+}
+}  // namespace
+
+extern "C" int rihip_embedding_scatter_add(float* grad_table, int64_t n_rows, const int64_t* ids, const float* dX,
+                                           int64_t B, int d, void* stream) {
+  RIHIP_REQUIRE(grad_table && ids && dX && d > 0, RIHIP_ERR_ARG, "embedding_scatter_add: null pointer");
+    if (B <= 0) return RIHIP_OK;
+  ScatterArgs a;
+  a.D = d;
+  a.t[0] = ScatterDesc{grad_table, n_rows, ids, dX, B};
+  a.t[1] = a.t[0];
+  return scatter_launch(a, 1, (hipStream_t)stream);
+}
+
+extern "C" int rihip_embedding_scatter_add2(float* grad_a, int64_t n_rows_a, const int64_t* ids_a, const float* dX_a,
+                                            int64_t B_a, float* grad_b, int64_t n_rows_b, const int64_t* ids_b,
+                                            const float* dX_b, int64_t B_b, int d, void* stream) {
+  RIHIP_REQUIRE(grad_a && ids_a && dX_a && grad_b && ids_b && dX_b && d > 0, RIHIP_ERR_ARG,
+                "embedding_scatter_add2: null pointer");
+  RIHIP_REQUIRE(grad_a != grad_b, RIHIP_ERR_ARG, "embedding_scatter_add2: the two tables must differ");
+  if (B_a <= 0 && B_b <= 0) return RIHIP_OK;
+  ScatterArgs a;
+  a.D = d;
+  a.t[0] = ScatterDesc{grad_a, n_rows_a, ids_a, dX_a, B_a > 0 ? B_a : 0};
+  a.t[1] = ScatterDesc{grad_b, n_rows_b, ids_b, dX_b, B_b > 0 ? B_b : 0};
+  return scatter_launch(a, 2, (hipStream_t)stream);
 }

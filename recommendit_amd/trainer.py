@@ -436,8 +436,11 @@ class HipBPRTrainer:
             cur.wait_stream(sideA)
         else:
             # dense tables (ML-1M scale): the table gradients were zeroed by the previous step's Adam launch
-            self.uopt.scatter(user_ids, self.dXu, st, zero=False)
-            self.iopt.scatter(iid, dXi, st, zero=False)
+            uo, io = self.uopt, self.iopt   # both tables in one launch
+            L.check(lib.rihip_embedding_scatter_add2(
+                uo.grad.data_ptr(), uo.table.shape[0], user_ids.data_ptr(), self.dXu.data_ptr(), user_ids.numel(),
+                io.grad.data_ptr(), io.table.shape[0], iid.data_ptr(), dXi.data_ptr(), iid.numel(), d, st),
+                "embedding_scatter_add2")
         n_part = o2 + self.np_rows
         if self.dist:
             # user rows are disjoint across ranks: their squared norms add; the MLP part is already global; the item

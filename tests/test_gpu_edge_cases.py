@@ -147,3 +147,53 @@ def test_rows_group_key_bits_hint_is_equivalent():
     ref = torch.zeros(n_rows, d, device=dev).index_add_(0, ids, dX)
     np.testing.assert_allclose(outs[0][1].cpu().numpy(), ref[outs[0][0]].cpu().numpy() * (outs[0][0] != 0).float()[:, None].cpu().numpy(),
                                atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,n_rows,d", [(1, 5, 32), (256, 40, 64), (8192, 3953, 64), (40000, 300, 128), (777, 97, 20),
+                                        (5000, 700_000, 32)])
+def test_dense_scatter_is_sequential_sum_bitwise(B, n_rows, d):
+    """rihip_embedding_scatter_add: every row receives its samples in batch order on top of its current contents --
+    the float32 result equals np.add.at (sequential) bit for bit, twice in a row (no floating-point atomics), with ids
+    outside [1, n_rows) skipped.  B = 40000 crosses the 16384-position pass; 700k rows need > 2 row ranges of 2^18."""
+    from recommendit_amd import _lib as L
+    lib, dev = L.lib(), L.device()
+    rng = np.random.default_rng(B + d)
+    ids = rng.integers(0, n_rows, size=B).astype(np.int64)     # includes padding id 0 and heavy repeats
+    if B > 10:
+        ids[3] = n_rows + 7; ids[5] = -2                        # out of range: skipped
+        ids[7] = n_rows - 1; ids[8] = 1                         # table boundary rows
+    dX = (rng.standard_normal((B, d)) * 10.0 ** rng.integers(-6, 1, size=(B, 1))).astype(np.float32)
+    g0 = rng.standard_normal((n_rows, d)).astype(np.float32) if n_rows < 10000 else np.zeros((n_rows, d), np.float32)
+    ref = g0.copy()
+    ok = (ids > 0) & (ids < n_rows)
+    np.add.at(ref, ids[ok], dX[ok])
+    tid, tdx = torch.from_numpy(ids).to(dev), torch.from_numpy(dX).to(dev)
+    outs = []
+    for _ in range(2):
+        g = torch.from_numpy(g0).to(dev)
+        L.check(lib.rihip_embedding_scatter_add(g.data_ptr(), n_rows, tid.data_ptr(), tdx.data_ptr(), B, d,
+                                                L.stream_ptr()), "scatter")
+        outs.append(g.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[0].view(np.uint32), ref.view(np.uint32))
+
+
+def test_dense_scatter_two_tables_one_call():
+    from recommendit_amd import _lib as L
+    lib, dev = L.lib(), L.device()
+    rng = np.random.default_rng(12)
+    d = 64
+    spec = [(300, 50), (20000, 900)]
+    dev_in, refs = [], []
+    for B, n in spec:
+        ids = rng.integers(0, n, size=B).astype(np.int64)
+        dX = rng.standard_normal((B, d)).astype(np.float32)
+        ref = np.full((n, d), 0.5, np.float32)                  # += onto existing contents
+        np.add.at(ref, ids[ids > 0], dX[ids > 0])
+        dev_in.append((torch.from_numpy(ids).to(dev), torch.from_numpy(dX).to(dev), torch.full((n, d), 0.5, device=dev)))
+        refs.append(ref)
+    (ia, xa, ga), (ib, xb, gb) = dev_in
+    L.check(lib.rihip_embedding_scatter_add2(ga.data_ptr(), spec[0][1], ia.data_ptr(), xa.data_ptr(), spec[0][0],
+                                             gb.data_ptr(), spec[1][1], ib.data_ptr(), xb.data_ptr(), spec[1][0],
+                                             d, L.stream_ptr()), "scatter2")
+    assert np.array_equal(ga.cpu().numpy(), refs[0]) and np.array_equal(gb.cpu().numpy(), refs[1])
