@@ -162,6 +162,12 @@ int rihip_adam_dense(float* p, const float* g, float* m, float* v, int64_t n, fl
  * Passing hyper_dev (non-NULL) to rihip_adam_dense / rihip_adam_rows overrides their host-side lr/step arguments. */
 int rihip_adam_hyper_step(int64_t* step_dev, const float* lr_dev, float beta1, float beta2, float* hyper_dev,
                           void* stream);
+/* The same clock folded into the launches a step makes anyway (a small-batch step costs ~5 us per dependent launch):
+ * rihip_clip_coef_step = rihip_clip_coef, then hyper_dev for t = *step_dev (the step that is running: initialise
+ * *step_dev to 1), then *step_dev = t + 1. */
+int rihip_clip_coef_step(const double* part, int64_t n_part, float max_norm, float* coef, float* total_norm,
+                         int64_t* step_dev, const float* lr_dev, float beta1, float beta2, float* hyper_dev,
+                         void* stream);
 
 /* Row-sparse path for tables too large for a dense pass per step (SURVEY.md §7 hard part 1):
  * group (id,sample) pairs by id (radix sort), sum each row's contributions in sorted order

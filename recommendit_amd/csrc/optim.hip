@@ -48,6 +48,31 @@ __global__ void clip_coef_kernel(const double* __restrict__ part, int n, float m
   }
 }
 
+// clip coefficient of this step + the step clock: hyper = {lr / (1 - b1^t), sqrt(1 - b2^t)} for t = *step (the step
+// that is running), then *step = t + 1 for the next step's kernels (dropout seed offset, this routine).  One thread.
+__device__ __forceinline__ void clip_and_clock(double sumsq, float max_norm, float* coef, float* norm, int64_t* step,
+                                               const float* lr, float b1, float b2, float* hyper) {
+  const float tn = (float)sqrt(sumsq);
+  const float c = max_norm / (tn + 1e-6f);
+  *coef = c < 1.f ? c : 1.f;
+  if (norm) *norm = tn;
+  if (step) {
+    const int64_t t = *step;
+    const double bc1 = 1.0 - pow((double)b1, (double)t);
+    const double bc2 = 1.0 - pow((double)b2, (double)t);
+    hyper[0] = (float)((double)(*lr) / bc1);
+    hyper[1] = (float)sqrt(bc2);
+    *step = t + 1;
+  }
+}
+__global__ void clip_coef_step_kernel(const double* __restrict__ part, int n, float max_norm, float* coef, float* norm,
+                                      int64_t* step, const float* lr, float b1, float b2, float* hyper) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) s += part[i];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) clip_and_clock(s, max_norm, coef, norm, step, lr, b1, b2, hyper);
+}
+
 struct AdamHyper {
   float lr_over_bc1;   // lr / (1 - b1^t)
   float sqrt_bc2;      // sqrt(1 - b2^t)
@@ -441,6 +466,16 @@ extern "C" int rihip_clip_coef(const double* part, int64_t n_part, float max_nor
   RIHIP_REQUIRE(part && coef && n_part > 0, RIHIP_ERR_ARG, "clip_coef: bad arguments");
   hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, part, (int)n_part, max_norm, coef,
                      total_norm);
+  RIHIP_CHECK_LAUNCH();
+  return RIHIP_OK;
+}
+
+extern "C" int rihip_clip_coef_step(const double* part, int64_t n_part, float max_norm, float* coef, float* total_norm,
+                                    int64_t* step_dev, const float* lr_dev, float beta1, float beta2, float* hyper_dev,
+                                    void* stream) {
+  RIHIP_REQUIRE(part && coef && n_part > 0 && step_dev && lr_dev && hyper_dev, RIHIP_ERR_ARG, "clip_coef_step: bad arguments");
+  hipLaunchKernelGGL(clip_coef_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, part, (int)n_part, max_norm, coef,
+                     total_norm, step_dev, lr_dev, beta1, beta2, hyper_dev);
   RIHIP_CHECK_LAUNCH();
   return RIHIP_OK;
 }

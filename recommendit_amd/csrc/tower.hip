@@ -77,8 +77,15 @@ __device__ __forceinline__ void load_frag_cols(f32x4 (&bf)[KB], const float* __r
 // fragment-major copy of a row-major weight W[N][K] (k contiguous): Wp[(ct*KB + kb)*64 + lane] = the float4 that
 // lane `lane` of the wave owning column tile ct feeds to the 4 MFMAs of k-block kb  => one coalesced 1 KB load per
 // wave-instruction instead of 64 strided 16-B pieces
-__global__ void pack_frag_rows_kernel(const float* __restrict__ W, int N, int K, int KB, f32x4* __restrict__ Wp) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// (both weight matrices of a tower in one launch: blocks [0, nb1) pack W1, the rest W2)
+__global__ void pack_frag_rows_kernel(const float* __restrict__ Wa, int Na, int Ka, int KBa, f32x4* __restrict__ Wpa,
+                                      int nb1, const float* __restrict__ Wb, int Nb, int Kb, int KBb,
+                                      f32x4* __restrict__ Wpb) {
+  const bool first = (int)blockIdx.x < nb1;
+  const float* __restrict__ W = first ? Wa : Wb;
+  f32x4* __restrict__ Wp = first ? Wpa : Wpb;
+  const int N = first ? Na : Nb, K = first ? Ka : Kb, KB = first ? KBa : KBb;
+  const int i = (first ? blockIdx.x : blockIdx.x - nb1) * blockDim.x + threadIdx.x;
   if (i >= (N / 32) * KB * 64) return;
   const int lane = i & 63, kb = (i >> 6) % KB, ct = (i >> 6) / KB;
   const int row = ct * 32 + (lane & 31), h = lane >> 5;
@@ -642,7 +649,7 @@ extern "C" int rihip_tower_forward(const float* table, int64_t n_rows, const int
       return RIHIP_OK;
     }
   }
-  // re-pack the (just updated) weights fragment-major: 2 tiny launches, coalesced loads in the kernel -- only worth
+  // re-pack the (just updated) weights fragment-major: one tiny launch, coalesced loads in the kernel -- only worth
   // it when many workgroups load them; a small batch is bounded by dependent kernel boundaries instead
   if (workspace && ntiles > 64) {
     const int K1 = d + (item ? 18 : 0), KB1 = (K1 + 7) / 8, KB2 = hidden / 8;
@@ -650,8 +657,9 @@ extern "C" int rihip_tower_forward(const float* table, int64_t n_rows, const int
     f32x4* w1p = reinterpret_cast<f32x4*>(workspace);
     f32x4* w2p = w1p + (size_t)(hidden / 32) * KB1 * 64;
     const int n1 = (hidden / 32) * KB1 * 64, n2 = (d / 32) * KB2 * 64;
-    hipLaunchKernelGGL(pack_frag_rows_kernel, dim3((n1 + 255) / 256), dim3(256), 0, st, W1, hidden, K1, KB1, w1p);
-    hipLaunchKernelGGL(pack_frag_rows_kernel, dim3((n2 + 255) / 256), dim3(256), 0, st, W2, d, hidden, KB2, w2p);
+    const int nb1 = (n1 + 255) / 256, nb2 = (n2 + 255) / 256;
+    hipLaunchKernelGGL(pack_frag_rows_kernel, dim3(nb1 + nb2), dim3(256), 0, st, W1, hidden, K1, KB1, w1p, nb1, W2, d,
+                       hidden, KB2, w2p);
     a.W1p = w1p; a.W2p = w2p;
   }
   DISPATCH_DH(launch_fwd, item, a, grid, st)

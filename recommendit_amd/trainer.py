@@ -201,7 +201,8 @@ class HipBPRTrainer:
         self.dXu = torch.empty((B, d), **f32); self.dXi = torch.empty((nI, d), **f32)
         self.loss = torch.zeros((), **f32)
         # device-resident step clock (graph replay must not bake host constants): step counter, lr, {lr/bc1, sqrt(bc2)}
-        self.step_dev = torch.zeros((1,), dtype=torch.int64, device=self.dev)
+        # (the clock is advanced by the clip-coefficient launch of each step: *step_dev = the step that is running)
+        self.step_dev = torch.ones((1,), dtype=torch.int64, device=self.dev)
         self.lr_dev = torch.full((1,), float(lr), **f32)
         self.hyper_dev = torch.zeros((2,), **f32)
         self._lr_host = float(lr)
@@ -319,8 +320,6 @@ class HipBPRTrainer:
     def _step_impl(self, user_ids: torch.Tensor, item_ids: torch.Tensor, item_genres: torch.Tensor) -> torch.Tensor:
         lib, B, d = self.lib, self.B, self.d
         self._st = st = L.stream_ptr()
-        L.check(lib.rihip_adam_hyper_step(self.step_dev.data_ptr(), self.lr_dev.data_ptr(), self.b1, self.b2,
-                                          self.hyper_dev.data_ptr(), st), "adam_hyper_step")
         t, lr = 0, 0.0   # the device clock (hyper_dev) overrides the host-side step / lr arguments below
         ukeys, ikeys = _MLP_KEYS[:4], _MLP_KEYS[4:]
         s0 = (self.seed * 1000003 + self.rank * 7919) & ((1 << 62) - 1)   # + device step counter inside the kernel
@@ -452,10 +451,12 @@ class HipBPRTrainer:
             if self.item_rows:
                 self.part[o2:n_part].zero_()
                 self.part[o2] = sq[1]
+        clock = (self.step_dev.data_ptr(), self.lr_dev.data_ptr(), self.b1, self.b2, self.hyper_dev.data_ptr())
         if dense:   # one launch for the three squared norms (MLP, user table, item table gradients)
             L.check(lib.rihip_sumsq_multi(3, self._mt_g, self._mt_n, pp, st), "sumsq_multi")
-        L.check(lib.rihip_clip_coef(pp, n_part, self.max_norm, self.coef.data_ptr(), self.gnorm.data_ptr(), st),
-                "clip_coef")
+        # clip coefficient + the step clock (Adam's bias-corrected step size of this step; counter advanced for the next)
+        L.check(lib.rihip_clip_coef_step(pp, n_part, self.max_norm, self.coef.data_ptr(), self.gnorm.data_ptr(),
+                                         *clock, st), "clip_coef_step")
         cp = self.coef.data_ptr()
         hp = self.hyper_dev.data_ptr()
         if dense:   # one Adam launch for MLP + both tables; it leaves the table gradients zeroed for the next scatter
