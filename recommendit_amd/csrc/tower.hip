@@ -469,31 +469,46 @@ __global__ void slab_reduce2_kernel(const float* __restrict__ part, int G, int P
 constexpr int SLAB_GROUPS = 16;
 
 // ---- dense embedding grad: grad[ids[b]] += dX[b]  (padding row 0 gets no gradient), bitwise reproducible.
-// Workgroup w of a table owns the row range [1 + w*R, 1 + (w+1)*R): it walks the batch in chunks of 16384 positions,
-// compacts the positions whose id falls in its range (in batch order), sorts the (row, position) keys in LDS and lets ONE
-// lane group add every run of equal rows to the table row, sample after sample in batch order, starting from the row's
-// current contents -- the float32 chain of index_add_ / np.add.at on a CPU.  No floating-point atomics.
+// Workgroup w of a table owns the rows with (id - 1) % nwg == w (popular rows of a skewed batch spread over the
+// workgroups): it walks the batch in passes of 16384 positions, compacts the positions whose id it owns (in batch
+// order), sorts the (row, position) keys in LDS and adds every run of equal rows to the table row sample after sample
+// in batch order, starting from the row's current contents -- the float32 chain of index_add_ / np.add.at on a CPU.
+// A short run is summed by one lane group straight from memory; a long one (a hot row) has its samples staged into LDS
+// by the whole workgroup, 1024 / (d/4) rows per round, and one lane group adds them in order.  No float atomics.
 constexpr int SCAT_CHUNK = 16384;     // batch positions per pass (14 bits of the key)
 constexpr int SCAT_RBITS = 18;        // rows per workgroup <= 2^18 (18 bits of the key)
+constexpr int SCAT_LONG = 48;         // runs longer than this are staged through LDS
 struct ScatterDesc {
   float* grad; int64_t n_rows; const int64_t* ids; const float* dX; int64_t B;
 };
-struct ScatterArgs { ScatterDesc t[2]; int D; int64_t rows_per_wg[2]; };
+struct ScatterArgs { ScatterDesc t[2]; int D; int nwg; };
 
-template <int LPR>   // lanes per row (float4 each); 0 = generic width, one lane per row looping over the columns
+__device__ __forceinline__ int scat_run_end(const uint32_t* keys, int i, int m, uint32_t rid) {
+  // first index > i whose row differs (keys sorted): lower_bound of (rid + 1) << 14
+  const uint32_t bound = (rid + 1u) << 14;
+  int lo_ = i + 1, hi_ = m;
+  while (lo_ < hi_) {
+    const int mid = (lo_ + hi_) >> 1;
+    if (keys[mid] < bound) lo_ = mid + 1; else hi_ = mid;
+  }
+  return lo_;
+}
+
+template <int LPR>   // lanes per row (float4 each); 0 = generic width, one lane per (run, column)
 __global__ __launch_bounds__(1024) void scatter_range_kernel(ScatterArgs a) {
   extern __shared__ uint32_t skeys[];
   __shared__ int wave_cnt[2][16];
-  const ScatterDesc& t = a.t[blockIdx.y];
-  const int64_t R = a.rows_per_wg[blockIdx.y];
-  const int64_t lo = 1 + (int64_t)blockIdx.x * R;
-  int64_t hi = lo + R;
-  if (hi > t.n_rows) hi = t.n_rows;
-  if (lo >= hi) return;   // workgroup-uniform
+  __shared__ int long_list[SCAT_CHUNK / SCAT_LONG + 1];
+  __shared__ int n_long;
+  __shared__ __attribute__((aligned(16))) float stage[LPR > 0 ? 4096 : 4];   // 1024 threads x float4
+  const ScatterDesc t = a.t[blockIdx.y];
+  const int nwg = a.nwg;
+  const int64_t own = blockIdx.x;
+  if (own + 1 >= t.n_rows) return;   // no row with (id - 1) % nwg == own   (workgroup-uniform)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (int64_t c0 = 0; c0 < t.B; c0 += SCAT_CHUNK) {
     const int n = (int)((t.B - c0 < SCAT_CHUNK) ? t.B - c0 : SCAT_CHUNK);
-    // ---- stable compaction of the chunk's positions that hit [lo, hi); all id loads of the pass are in flight together
+    // ---- stable compaction of the pass's positions whose row this workgroup owns; all id loads are in flight together
     int64_t idv[SCAT_CHUNK / 1024];
 #pragma unroll
     for (int it = 0; it < SCAT_CHUNK / 1024; ++it) {
@@ -505,7 +520,7 @@ __global__ __launch_bounds__(1024) void scatter_range_kernel(ScatterArgs a) {
     for (int it = 0; it < SCAT_CHUNK / 1024; ++it) {
       if (it * 1024 >= n) break;   // uniform
       const int64_t id = idv[it];
-      const bool in = id >= lo && id < hi;
+      const bool in = id >= 1 && id < t.n_rows && (id - 1) % nwg == own;
       const uint64_t bal = __ballot(in);
       if (lane == 0) wave_cnt[it & 1][w] = __popcll(bal);
       __syncthreads();
@@ -517,9 +532,11 @@ __global__ __launch_bounds__(1024) void scatter_range_kernel(ScatterArgs a) {
         total += c;
       }
       if (in)
-        skeys[m + before + __popcll(bal & ((1ull << lane) - 1ull))] = ((uint32_t)(id - lo) << 14) | (uint32_t)(it * 1024 + tid);
+        skeys[m + before + __popcll(bal & ((1ull << lane) - 1ull))] =
+            ((uint32_t)((id - 1) / nwg) << 14) | (uint32_t)(it * 1024 + tid);
       m += total;
     }
+    if (tid == 0) n_long = 0;
     if (m == 0) { __syncthreads(); continue; }   // uniform
     int np2 = 2;
     while (np2 < m) np2 <<= 1;
@@ -546,21 +563,51 @@ __global__ __launch_bounds__(1024) void scatter_range_kernel(ScatterArgs a) {
     // ---- runs of equal rows: sequential float32 chain onto the table row
     const float* base = t.dX + (size_t)c0 * a.D;
     if (LPR > 0) {
-      constexpr int D = LPR * 4, GPB = 1024 / (LPR > 0 ? LPR : 1);
-      const int g = tid / (LPR > 0 ? LPR : 1), c4 = tid % (LPR > 0 ? LPR : 1);
+      constexpr int LP = LPR > 0 ? LPR : 1;
+      constexpr int D = LP * 4, GPB = 1024 / LP;
+      const int g = tid / LP, c4 = tid % LP;
       for (int i = g; i < m; i += GPB) {
         const uint32_t key = skeys[i];
         const uint32_t rid = key >> 14;
         if (i > 0 && (skeys[i - 1] >> 14) == rid) continue;   // not the head of a run
-        f32x4* dst = reinterpret_cast<f32x4*>(t.grad + (size_t)(lo + rid) * D) + c4;
+        const int end = scat_run_end(skeys, i, m, rid);
+        if (end - i > SCAT_LONG) {
+          if (c4 == 0) long_list[atomicAdd(&n_long, 1)] = i;   // different rows: the order of this list is immaterial
+          continue;
+        }
+        f32x4* dst = reinterpret_cast<f32x4*>(t.grad + (size_t)((int64_t)rid * nwg + own + 1) * D) + c4;
         f32x4 acc = *dst;
-        for (int j = i; j < m; ++j) {
-          const uint32_t kj = skeys[j];
-          if ((kj >> 14) != rid) break;
-          const f32x4 v = reinterpret_cast<const f32x4*>(base + (size_t)(kj & 16383u) * D)[c4];
+        for (int j = i; j < end; ++j) {
+          const f32x4 v = reinterpret_cast<const f32x4*>(base + (size_t)(skeys[j] & 16383u) * D)[c4];
           acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
         *dst = acc;
+      }
+      __syncthreads();
+      const int nl = n_long;
+      for (int q = 0; q < nl; ++q) {   // hot rows: uniform loop, the whole workgroup stages, lane group 0 adds
+        const int i = long_list[q];
+        const uint32_t rid = skeys[i] >> 14;
+        const int end = scat_run_end(skeys, i, m, rid);
+        f32x4* dst = reinterpret_cast<f32x4*>(t.grad + (size_t)((int64_t)rid * nwg + own + 1) * D) + c4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (g == 0) acc = *dst;
+        for (int r0 = i; r0 < end; r0 += GPB) {
+          const int r = r0 + g;
+          if (r < end)
+            reinterpret_cast<f32x4*>(stage)[g * LP + c4] =
+                reinterpret_cast<const f32x4*>(base + (size_t)(skeys[r] & 16383u) * D)[c4];
+          __syncthreads();
+          if (g == 0) {
+            const int cnt = (end - r0 < GPB) ? end - r0 : GPB;
+            for (int x = 0; x < cnt; ++x) {
+              const f32x4 v = reinterpret_cast<const f32x4*>(stage)[x * LP + c4];
+              acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+          }
+          __syncthreads();
+        }
+        if (g == 0) *dst = acc;
       }
     } else {
       const int D = a.D;
@@ -568,7 +615,7 @@ __global__ __launch_bounds__(1024) void scatter_range_kernel(ScatterArgs a) {
         const int i = e / D, c = e % D;
         const uint32_t rid = skeys[i] >> 14;
         if (i > 0 && (skeys[i - 1] >> 14) == rid) continue;
-        float* dst = t.grad + (size_t)(lo + rid) * D + c;
+        float* dst = t.grad + (size_t)((int64_t)rid * nwg + own + 1) * D + c;
         float acc = *dst;
         for (int j = i; j < m; ++j) {
           const uint32_t kj = skeys[j];
@@ -578,7 +625,7 @@ __global__ __launch_bounds__(1024) void scatter_range_kernel(ScatterArgs a) {
         *dst = acc;
       }
     }
-    __syncthreads();   // the next chunk's keys overwrite skeys; its row updates follow this chunk's (same workgroup)
+    __syncthreads();   // the next pass's keys overwrite skeys; its row updates follow this pass's (same workgroup)
   }
 }
 
@@ -758,7 +805,7 @@ int scatter_launch(ScatterArgs a, int n_tables, hipStream_t st) {
     want = need > want ? need : want;
   }
   nwg = (int)want;
-  for (int t = 0; t < n_tables; ++t) a.rows_per_wg[t] = (a.t[t].n_rows - 1 + nwg - 1) / nwg > 0 ? (a.t[t].n_rows - 1 + nwg - 1) / nwg : 1;
+  a.nwg = nwg;
   int np2 = 64;
   const int64_t cap = maxB < SCAT_CHUNK ? maxB : SCAT_CHUNK;
   while (np2 < cap) np2 <<= 1;

@@ -154,11 +154,16 @@ def test_rows_group_key_bits_hint_is_equivalent():
 def test_dense_scatter_is_sequential_sum_bitwise(B, n_rows, d):
     """rihip_embedding_scatter_add: every row receives its samples in batch order on top of its current contents --
     the float32 result equals np.add.at (sequential) bit for bit, twice in a row (no floating-point atomics), with ids
-    outside [1, n_rows) skipped.  B = 40000 crosses the 16384-position pass; 700k rows need > 2 row ranges of 2^18."""
+    outside [1, n_rows) skipped.  B = 40000 crosses the 16384-position pass; 700k rows need > 2 owners of 2^18 rows; the
+    skewed cases take the LDS-staged path for hot rows."""
     from recommendit_amd import _lib as L
     lib, dev = L.lib(), L.device()
     rng = np.random.default_rng(B + d)
     ids = rng.integers(0, n_rows, size=B).astype(np.int64)     # includes padding id 0 and heavy repeats
+    if B == 8192:                                                # skewed batch: hot rows with hundreds of samples
+        ids = np.minimum(rng.zipf(1.05, size=B), n_rows - 1).astype(np.int64)
+    if B == 40000:                                               # one row takes a third of the batch
+        ids[rng.random(B) < 0.33] = 17
     if B > 10:
         ids[3] = n_rows + 7; ids[5] = -2                        # out of range: skipped
         ids[7] = n_rows - 1; ids[8] = 1                         # table boundary rows
