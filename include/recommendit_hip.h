@@ -79,6 +79,18 @@ int rihip_tower_backward_ev(const float* table, int64_t n_rows, const int64_t* i
                             const float* out, const float* denom, const float* hid, float dropout_scale, float* dX,
                             float* dW1, float* db1, float* dW2, float* db2, int accumulate, float* workspace,
                             void* stream, void* dx_event);
+/* The backward in two halves, for a step with two towers: _partial launches the gradient kernels only (dX complete,
+ * weight-gradient slabs left in `workspace`, their count in *n_slabs); _reduce2 then sums the slabs of BOTH towers
+ * (b may be absent: ws_b = NULL) in one pair of launches -- the same sums in the same order as rihip_tower_backward,
+ * so the results are bit-identical.  The two towers need separate workspaces. */
+int rihip_tower_backward_partial(const float* table, int64_t n_rows, const int64_t* ids, const float* genres, int64_t B,
+                                 int d, int hidden, const float* W1, const float* W2, const float* grad_out,
+                                 const float* out, const float* denom, const float* hid, float dropout_scale,
+                                 float* dX, float* workspace, void* stream, void* dx_event, int* n_slabs);
+int rihip_tower_backward_reduce2(int d, int hidden, float* ws_a, int64_t B_a, int item_a, int n_slabs_a, float* dW1_a,
+                                 float* db1_a, float* dW2_a, float* db2_a, float* ws_b, int64_t B_b, int item_b,
+                                 int n_slabs_b, float* dW1_b, float* db1_b, float* dW2_b, float* db2_b, int accumulate,
+                                 void* stream);
 
 /* nn.Embedding backward (dense): grad_table[ids[b]] += dX[b]; row 0 (padding_idx, two_tower.py:27,54) and ids outside
  * [1, n_rows) are skipped.  Bitwise reproducible: every row receives its samples one after the other in batch order,
@@ -92,9 +104,12 @@ int rihip_embedding_scatter_add2(float* grad_a, int64_t n_rows_a, const int64_t*
 
 /* ---- losses --------------------------------------------------------------------------------
  * rihip_bpr_pair_loss replaces TwoTowerModel.bpr_loss (two_tower.py:117-130) and its backward:
- * loss = mean softplus(-(u.p - u.n)); dU,dP,dN = d loss / d inputs.  workspace: >=1024 doubles. */
+ * loss = mean softplus(-(u.p - u.n)); dU,dP,dN = d loss / d inputs.  workspace: >=1024 doubles.
+ * loss may be NULL: the value is then (1/B) * sum(workspace[0 .. rihip_bpr_pair_nparts(B))), summed later by the
+ * caller (rihip_sum_partials / rihip_clip_coef_step). */
 int rihip_bpr_pair_loss(const float* U, const float* P, const float* N, int64_t B, int d, float* loss, float* dU,
                         float* dP, float* dN, double* workspace, void* stream);
+int64_t rihip_bpr_pair_nparts(int64_t B);
 
 /* In-batch-negative BPR (TwoTowerModel.in_batch_bpr_loss, two_tower.py:132-160, closed form
  *   L = 1/(B(B-1)) sum_i sum_{j!=i} softplus(s_ij - s_ii)) is three calls:
@@ -164,10 +179,11 @@ int rihip_adam_hyper_step(int64_t* step_dev, const float* lr_dev, float beta1, f
                           void* stream);
 /* The same clock folded into the launches a step makes anyway (a small-batch step costs ~5 us per dependent launch):
  * rihip_clip_coef_step = rihip_clip_coef, then hyper_dev for t = *step_dev (the step that is running: initialise
- * *step_dev to 1), then *step_dev = t + 1. */
+ * *step_dev to 1), then *step_dev = t + 1.  loss_part (nullable): *loss = loss_scale * sum(loss_part[0..n)) as well --
+ * the loss partials of rihip_bpr_pair_loss(loss = NULL) / the in-batch passes, summed off the critical path. */
 int rihip_clip_coef_step(const double* part, int64_t n_part, float max_norm, float* coef, float* total_norm,
                          int64_t* step_dev, const float* lr_dev, float beta1, float beta2, float* hyper_dev,
-                         void* stream);
+                         const double* loss_part, int64_t n_loss_part, double loss_scale, float* loss, void* stream);
 
 /* Row-sparse path for tables too large for a dense pass per step (SURVEY.md §7 hard part 1):
  * group (id,sample) pairs by id (radix sort), sum each row's contributions in sorted order

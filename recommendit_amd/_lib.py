@@ -60,7 +60,13 @@ SIGNATURES = {
     "rihip_adam_dense": (C.c_int, [vp, vp, vp, vp, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, c_i64,
                                    vp, vp, vp]),
     "rihip_adam_hyper_step": (C.c_int, [vp, vp, C.c_float, C.c_float, vp, vp]),
-    "rihip_clip_coef_step": (C.c_int, [vp, c_i64, C.c_float, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp]),
+    "rihip_clip_coef_step": (C.c_int, [vp, c_i64, C.c_float, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, c_i64,
+                                       C.c_double, vp, vp]),
+    "rihip_bpr_pair_nparts": (c_i64, [c_i64]),
+    "rihip_tower_backward_partial": (C.c_int, [vp, c_i64, vp, vp, c_i64, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp,
+                                               C.c_float, vp, vp, vp, vp, vp]),
+    "rihip_tower_backward_reduce2": (C.c_int, [C.c_int, C.c_int, vp, c_i64, C.c_int, C.c_int, vp, vp, vp, vp, vp, c_i64,
+                                               C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp]),
     "rihip_rows_workspace_bytes": (c_i64, [c_i64, C.c_int]),
     "rihip_rows_nparts": (C.c_int, []),
     "rihip_rows_group": (C.c_int, [vp, c_i64, C.c_int, c_i64, vp, vp, c_i64, vp]),

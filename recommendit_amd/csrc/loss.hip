@@ -563,7 +563,7 @@ int sweep_nsplit(int64_t n_owner, int64_t n_swept, int nw = 4) {
 
 extern "C" int rihip_bpr_pair_loss(const float* U, const float* P, const float* N, int64_t B, int d, float* loss,
                                    float* dU, float* dP, float* dN, double* workspace, void* stream) {
-  RIHIP_REQUIRE(U && P && N && loss && dU && dP && dN && workspace, RIHIP_ERR_ARG, "bpr_pair_loss: null pointer");
+  RIHIP_REQUIRE(U && P && N && dU && dP && dN && workspace, RIHIP_ERR_ARG, "bpr_pair_loss: null pointer");
   RIHIP_REQUIRE(B > 0 && d > 0, RIHIP_ERR_ARG, "bpr_pair_loss: bad sizes B=%lld d=%d", (long long)B, d);
   hipStream_t st = (hipStream_t)stream;
   const int64_t nb = (B + 3) / 4;
@@ -576,9 +576,16 @@ extern "C" int rihip_bpr_pair_loss(const float* U, const float* P, const float* 
   else if (al && d == 32) hipLaunchKernelGGL((bpr_pair_v4_kernel<8>), dim3(grid), dim3(256), 0, st, U, P, N, B, inv_B, dU, dP, dN, workspace);
   else hipLaunchKernelGGL(bpr_pair_kernel, dim3(grid), dim3(256), 0, st, U, P, N, B, d, inv_B, dU, dP, dN, workspace);
   RIHIP_CHECK_LAUNCH();
-  hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(64), 0, st, workspace, grid, 1.0 / (double)B, loss);
+  // loss == NULL: the caller sums workspace[0 .. rihip_bpr_pair_nparts(B)) * (1/B) itself (rihip_sum_partials or
+  // rihip_clip_coef_step) -- one dependent launch less on the step's critical path
+  if (loss) hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(64), 0, st, workspace, grid, 1.0 / (double)B, loss);
   RIHIP_CHECK_LAUNCH();
   return RIHIP_OK;
+}
+
+extern "C" int64_t rihip_bpr_pair_nparts(int64_t B) {
+  const int64_t nb = (B + 3) / 4;
+  return nb < 1024 ? (nb > 0 ? nb : 1) : 1024;
 }
 
 extern "C" int rihip_rowdot(const float* U, const float* I, int64_t B, int64_t i_offset, int d, float* pos,

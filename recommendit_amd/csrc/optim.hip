@@ -65,12 +65,30 @@ __device__ __forceinline__ void clip_and_clock(double sumsq, float max_norm, flo
     *step = t + 1;
   }
 }
-__global__ void clip_coef_step_kernel(const double* __restrict__ part, int n, float max_norm, float* coef, float* norm,
-                                      int64_t* step, const float* lr, float b1, float b2, float* hyper) {
-  double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += 64) s += part[i];
+// 1024 threads: a step has up to a few thousand partials (MLP + two row-sparse tables) and this single workgroup sits
+// on the step's critical path -- 64 threads took 14-22 us for them, latency-bound
+__global__ __launch_bounds__(1024) void clip_coef_step_kernel(const double* __restrict__ part, int n, float max_norm,
+                                                              float* coef, float* norm, int64_t* step, const float* lr,
+                                                              float b1, float b2, float* hyper,
+                                                              const double* __restrict__ loss_part, int n_loss,
+                                                              double loss_scale, float* loss) {
+  __shared__ double sh[2][16];
+  const int tid = threadIdx.x;
+  double s = 0.0, l = 0.0;
+  for (int i = tid; i < n; i += 1024) s += part[i];
+  if (loss_part)
+    for (int i = tid; i < n_loss; i += 1024) l += loss_part[i];
   s = wave_sum_d(s);
-  if (threadIdx.x == 0) clip_and_clock(s, max_norm, coef, norm, step, lr, b1, b2, hyper);
+  l = wave_sum_d(l);
+  if ((tid & 63) == 0) { sh[0][tid >> 6] = s; sh[1][tid >> 6] = l; }
+  __syncthreads();
+  if (tid == 0) {
+    double st = 0.0, lt = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { st += sh[0][w]; lt += sh[1][w]; }   // fixed order
+    clip_and_clock(st, max_norm, coef, norm, step, lr, b1, b2, hyper);
+    if (loss_part) *loss = (float)(lt * loss_scale);   // the loss value of the step, off the critical path
+  }
 }
 
 struct AdamHyper {
@@ -472,10 +490,12 @@ extern "C" int rihip_clip_coef(const double* part, int64_t n_part, float max_nor
 
 extern "C" int rihip_clip_coef_step(const double* part, int64_t n_part, float max_norm, float* coef, float* total_norm,
                                     int64_t* step_dev, const float* lr_dev, float beta1, float beta2, float* hyper_dev,
+                                    const double* loss_part, int64_t n_loss_part, double loss_scale, float* loss,
                                     void* stream) {
   RIHIP_REQUIRE(part && coef && n_part > 0 && step_dev && lr_dev && hyper_dev, RIHIP_ERR_ARG, "clip_coef_step: bad arguments");
-  hipLaunchKernelGGL(clip_coef_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, part, (int)n_part, max_norm, coef,
-                     total_norm, step_dev, lr_dev, beta1, beta2, hyper_dev);
+  RIHIP_REQUIRE(!loss_part || (loss && n_loss_part > 0), RIHIP_ERR_ARG, "clip_coef_step: loss partials without an output");
+  hipLaunchKernelGGL(clip_coef_step_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, part, (int)n_part, max_norm, coef,
+                     total_norm, step_dev, lr_dev, beta1, beta2, hyper_dev, loss_part, (int)n_loss_part, loss_scale, loss);
   RIHIP_CHECK_LAUNCH();
   return RIHIP_OK;
 }

@@ -444,28 +444,6 @@ __global__ __launch_bounds__(256) void tower_bwd_kernel(TowerBwdArgs a) {
 // grads (+)= sum over slabs, two levels, fixed order => deterministic
 //   level 1: group g sums slabs g, g+G, g+2G, ...  -> part[g][P]      (grid.y = G)
 //   level 2: sums the G partials and routes element i to dW1 | db1 | dW2 | db2
-__global__ void slab_reduce1_kernel(const float* __restrict__ slab, int nslab, int P, int G, float* part) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P) return;
-  const int g = blockIdx.y;
-  float s = 0.f;
-  for (int k = g; k < nslab; k += G) s += slab[(size_t)k * P + i];
-  part[(size_t)g * P + i] = s;
-}
-__global__ void slab_reduce2_kernel(const float* __restrict__ part, int G, int P, int H, int K1, int D, float* dW1,
-                                    float* db1, float* dW2, float* db2, int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P) return;
-  float s = 0.f;
-  for (int g = 0; g < G; ++g) s += part[(size_t)g * P + i];
-  float* dst;
-  int off;
-  if (i < H * K1) { dst = dW1; off = i; }
-  else if (i < H * K1 + H) { dst = db1; off = i - H * K1; }
-  else if (i < H * K1 + H + D * H) { dst = dW2; off = i - H * K1 - H; }
-  else { dst = db2; off = i - H * K1 - H - D * H; }
-  dst[off] = accumulate ? dst[off] + s : s;
-}
 constexpr int SLAB_GROUPS = 16;
 
 // ---- dense embedding grad: grad[ids[b]] += dX[b]  (padding row 0 gets no gradient), bitwise reproducible.
@@ -728,20 +706,58 @@ extern "C" int64_t rihip_tower_backward_workspace_floats(int64_t B, int d, int h
   return ((grid > 0 ? grid : 1) + SLAB_GROUPS) * P + B * (int64_t)(d + hidden);
 }
 
-extern "C" int rihip_tower_backward_ev(const float* table, int64_t n_rows, const int64_t* ids, const float* genres,
-                                       int64_t B, int d, int hidden, const float* W1, const float* W2,
-                                       const float* grad_out, const float* out, const float* denom, const float* hid,
-                                       float dropout_scale, float* dX, float* dW1, float* db1, float* dW2, float* db2,
-                                       int accumulate, float* workspace, void* stream, void* dx_event) {
+namespace {
+struct SlabDesc { const float* slab; float* part; int nslab, P, K1; float *dW1, *db1, *dW2, *db2; };
+struct SlabArgs { SlabDesc t[2]; int H, D, accumulate; };
+// the two levels of slab_reduce1/2_kernel for up to two towers per launch (blockIdx.z picks the tower)
+__global__ void slab_reduce1_multi_kernel(SlabArgs a) {
+  const SlabDesc& t = a.t[blockIdx.z];
+  const int G = t.nslab < SLAB_GROUPS ? t.nslab : SLAB_GROUPS;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = blockIdx.y;
+  if (i >= t.P || g >= G || t.nslab <= SLAB_GROUPS) return;
+  float s = 0.f;
+  for (int k = g; k < t.nslab; k += G) s += t.slab[(size_t)k * t.P + i];
+  t.part[(size_t)g * t.P + i] = s;
+}
+__global__ void slab_reduce2_multi_kernel(SlabArgs a) {
+  const SlabDesc& t = a.t[blockIdx.z];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= t.P) return;
+  const int G = t.nslab < SLAB_GROUPS ? t.nslab : SLAB_GROUPS;
+  const float* part = t.nslab > SLAB_GROUPS ? t.part : t.slab;   // <= SLAB_GROUPS slabs: level 1 would be a copy
+  float s = 0.f;
+  for (int g = 0; g < G; ++g) s += part[(size_t)g * t.P + i];
+  const int H = a.H, D = a.D, K1 = t.K1;
+  float* dst;
+  int off;
+  if (i < H * K1) { dst = t.dW1; off = i; }
+  else if (i < H * K1 + H) { dst = t.db1; off = i - H * K1; }
+  else if (i < H * K1 + H + D * H) { dst = t.dW2; off = i - H * K1 - H; }
+  else { dst = t.db2; off = i - H * K1 - H - D * H; }
+  dst[off] = a.accumulate ? dst[off] + s : s;
+}
+inline float* slab_part_of(float* workspace, int64_t B, int P) {
+  const int64_t nt32 = (B + 31) / 32;
+  const int grid_ws = (int)(nt32 < RIHIP_NCU ? nt32 : RIHIP_NCU);   // slab slots in the workspace layout
+  return workspace + (size_t)(grid_ws > 0 ? grid_ws : 1) * P;
+}
+}  // namespace
+
+extern "C" int rihip_tower_backward_partial(const float* table, int64_t n_rows, const int64_t* ids, const float* genres,
+                                            int64_t B, int d, int hidden, const float* W1, const float* W2,
+                                            const float* grad_out, const float* out, const float* denom,
+                                            const float* hid, float dropout_scale, float* dX, float* workspace,
+                                            void* stream, void* dx_event, int* n_slabs) {
   RIHIP_REQUIRE(rihip_tower_supported(d, hidden), RIHIP_ERR_SHAPE,
                 "tower_backward: unsupported (embed_dim=%d, hidden_dim=%d)", d, hidden);
+  RIHIP_REQUIRE(n_slabs, RIHIP_ERR_ARG, "tower_backward: null pointer");
+  *n_slabs = 0;
   if (B <= 0) return RIHIP_OK;
-  RIHIP_REQUIRE(table && ids && W1 && W2 && grad_out && out && denom && hid && dX && dW1 && db1 && dW2 && db2 &&
-                    workspace,
-                RIHIP_ERR_ARG, "tower_backward: null pointer");
+  RIHIP_REQUIRE(table && ids && W1 && W2 && grad_out && out && denom && hid && dX && workspace, RIHIP_ERR_ARG,
+                "tower_backward: null pointer");
   RIHIP_REQUIRE(aligned16(table) && aligned16(grad_out) && aligned16(out) && aligned16(hid), RIHIP_ERR_ARG,
                 "tower_backward: table/grad_out/out/hid must be 16-byte aligned");
-  if (B <= 0) return RIHIP_OK;
   TowerBwdArgs a;
   a.table = table; a.n_rows = n_rows; a.ids = ids; a.genres = genres; a.B = B; a.W1 = W1; a.W2 = W2;
   a.gout = grad_out; a.out = out; a.denom = denom; a.hid = hid; a.scale = dropout_scale; a.dX = dX; a.slab = workspace;
@@ -751,9 +767,7 @@ extern "C" int rihip_tower_backward_ev(const float* table, int64_t n_rows, const
   hipStream_t st = (hipStream_t)stream;
   const int K1 = d + (item ? 18 : 0);
   const int P = hidden * K1 + hidden + d * hidden + d;
-  const int64_t nt32 = (B + 31) / 32;
-  const int grid_ws = (int)(nt32 < RIHIP_NCU ? nt32 : RIHIP_NCU);   // slab slots in the workspace layout
-  float* part = workspace + (size_t)(grid_ws > 0 ? grid_ws : 1) * P;
+  float* part = slab_part_of(workspace, B, P);
   float* act = part + (size_t)SLAB_GROUPS * P;
   int nslab = 0;
   {  // two-kernel backward (tower2.hip) for chip-filling batches; 1 = the fused 64-row-tile kernel
@@ -768,15 +782,52 @@ extern "C" int rihip_tower_backward_ev(const float* table, int64_t n_rows, const
     if (dx_event) (void)hipEventRecord((hipEvent_t)dx_event, st);
   }
   RIHIP_CHECK_LAUNCH();
-  const int G = nslab < SLAB_GROUPS ? nslab : SLAB_GROUPS;
-  if (nslab > SLAB_GROUPS)
-    hipLaunchKernelGGL(slab_reduce1_kernel, dim3((P + 255) / 256, G), dim3(256), 0, st, workspace, nslab, P, G, part);
-  else
-    part = workspace;  // at most SLAB_GROUPS slabs: level 1 would be a copy (same summation order either way)
-  hipLaunchKernelGGL(slab_reduce2_kernel, dim3((P + 255) / 256), dim3(256), 0, st, part, G, P, hidden, K1, d, dW1, db1,
-                     dW2, db2, accumulate);
+  *n_slabs = nslab;
+  return RIHIP_OK;
+}
+
+extern "C" int rihip_tower_backward_reduce2(int d, int hidden, float* ws_a, int64_t B_a, int item_a, int n_slabs_a,
+                                            float* dW1_a, float* db1_a, float* dW2_a, float* db2_a, float* ws_b,
+                                            int64_t B_b, int item_b, int n_slabs_b, float* dW1_b, float* db1_b,
+                                            float* dW2_b, float* db2_b, int accumulate, void* stream) {
+  RIHIP_REQUIRE(ws_a && dW1_a && db1_a && dW2_a && db2_a && n_slabs_a > 0 && B_a > 0, RIHIP_ERR_ARG,
+                "tower_backward_reduce2: bad arguments (tower a)");
+  const bool two = ws_b != nullptr && n_slabs_b > 0;
+  RIHIP_REQUIRE(!two || (dW1_b && db1_b && dW2_b && db2_b && B_b > 0 && ws_b != ws_a), RIHIP_ERR_ARG,
+                "tower_backward_reduce2: bad arguments (tower b)");
+  SlabArgs a;
+  a.H = hidden; a.D = d; a.accumulate = accumulate;
+  const int K1a = d + (item_a ? 18 : 0), Pa = hidden * K1a + hidden + d * hidden + d;
+  a.t[0] = SlabDesc{ws_a, slab_part_of(ws_a, B_a, Pa), n_slabs_a, Pa, K1a, dW1_a, db1_a, dW2_a, db2_a};
+  a.t[1] = a.t[0];
+  int Pmax = Pa, nmax = n_slabs_a;
+  if (two) {
+    const int K1b = d + (item_b ? 18 : 0), Pb = hidden * K1b + hidden + d * hidden + d;
+    a.t[1] = SlabDesc{ws_b, slab_part_of(ws_b, B_b, Pb), n_slabs_b, Pb, K1b, dW1_b, db1_b, dW2_b, db2_b};
+    Pmax = Pb > Pmax ? Pb : Pmax;
+    nmax = n_slabs_b > nmax ? n_slabs_b : nmax;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned nt = two ? 2 : 1;
+  if (nmax > SLAB_GROUPS)
+    hipLaunchKernelGGL(slab_reduce1_multi_kernel, dim3((Pmax + 255) / 256, SLAB_GROUPS, nt), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(slab_reduce2_multi_kernel, dim3((Pmax + 255) / 256, 1, nt), dim3(256), 0, st, a);
   RIHIP_CHECK_LAUNCH();
   return RIHIP_OK;
+}
+
+extern "C" int rihip_tower_backward_ev(const float* table, int64_t n_rows, const int64_t* ids, const float* genres,
+                                       int64_t B, int d, int hidden, const float* W1, const float* W2,
+                                       const float* grad_out, const float* out, const float* denom, const float* hid,
+                                       float dropout_scale, float* dX, float* dW1, float* db1, float* dW2, float* db2,
+                                       int accumulate, float* workspace, void* stream, void* dx_event) {
+  RIHIP_REQUIRE(B <= 0 || (dW1 && db1 && dW2 && db2), RIHIP_ERR_ARG, "tower_backward: null pointer");
+  int nslab = 0;
+  const int rc = rihip_tower_backward_partial(table, n_rows, ids, genres, B, d, hidden, W1, W2, grad_out, out, denom, hid,
+                                              dropout_scale, dX, workspace, stream, dx_event, &nslab);
+  if (rc != RIHIP_OK || nslab == 0) return rc;
+  return rihip_tower_backward_reduce2(d, hidden, workspace, B, genres != nullptr, nslab, dW1, db1, dW2, db2, nullptr, 0, 0,
+                                      0, nullptr, nullptr, nullptr, nullptr, accumulate, stream);
 }
 
 extern "C" int rihip_tower_backward(const float* table, int64_t n_rows, const int64_t* ids, const float* genres,

@@ -26,10 +26,9 @@ is an all-reduced scalar.  See DESIGN.md "Multi-GPU".
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 from typing import Dict, Optional
-
-import ctypes as C
 
 import torch
 import torch.distributed as dist
@@ -208,9 +207,9 @@ class HipBPRTrainer:
         self._lr_host = float(lr)
         self.coef = torch.ones((1,), **f32); self.gnorm = torch.zeros((1,), **f32)
         self.err = torch.zeros((1,), dtype=torch.int32, device=self.dev)
-        nws = max(self.lib.rihip_tower_backward_workspace_floats(B, d, H, 0),
-                  self.lib.rihip_tower_backward_workspace_floats(nI, d, H, 1))
-        self.bws = torch.empty((nws,), **f32)
+        self.bws_u = torch.empty((self.lib.rihip_tower_backward_workspace_floats(B, d, H, 0),), **f32)
+        self.bws_i = torch.empty((self.lib.rihip_tower_backward_workspace_floats(nI, d, H, 1),), **f32)
+        self._nslab = [(0, 0), (0, 0)]
         self.fws_u = torch.empty((self.lib.rihip_tower_forward_workspace_floats(d, H, 0),), **f32)
         self.fws_i = torch.empty((self.lib.rihip_tower_forward_workspace_floats(d, H, 1),), **f32)
         self.np_mlp = self.lib.rihip_sumsq_nparts()
@@ -278,13 +277,24 @@ class HipBPRTrainer:
             if not dx_event.cuda_event:      # the handle only exists after a first record
                 dx_event.record(torch.cuda.current_stream(self.dev))
             ev = dx_event.cuda_event
-        L.check(self.lib.rihip_tower_backward_ev(table.data_ptr(), table.shape[0], ids.data_ptr(), L.ptr(genres),
-                                              ids.numel(), self.d, self.H, self.pv[keys[0]].data_ptr(),
-                                              self.pv[keys[2]].data_ptr(), gout.data_ptr(), out.data_ptr(),
-                                              den.data_ptr(), hid.data_ptr(), scale, dX.data_ptr(),
-                                              self.gv[keys[0]].data_ptr(), self.gv[keys[1]].data_ptr(),
-                                              self.gv[keys[2]].data_ptr(), self.gv[keys[3]].data_ptr(), 0,
-                                              self.bws.data_ptr(), self._st, ev), "tower_backward")
+        # gradient kernels only: the weight-gradient slabs of the two towers are summed together by _bwd_reduce (one
+        # pair of launches for both, after the item tower -- the user tower's reduce is off the critical path)
+        ws = self.bws_u if genres is None else self.bws_i
+        n = C.c_int(0)
+        L.check(self.lib.rihip_tower_backward_partial(table.data_ptr(), table.shape[0], ids.data_ptr(), L.ptr(genres),
+                                                      ids.numel(), self.d, self.H, self.pv[keys[0]].data_ptr(),
+                                                      self.pv[keys[2]].data_ptr(), gout.data_ptr(), out.data_ptr(),
+                                                      den.data_ptr(), hid.data_ptr(), scale, dX.data_ptr(),
+                                                      ws.data_ptr(), self._st, ev, C.byref(n)), "tower_backward")
+        self._nslab[0 if genres is None else 1] = (n.value, ids.numel())
+
+    def _bwd_reduce(self, ukeys, ikeys):
+        (nu, bu), (ni, bi) = self._nslab
+        g = self.gv
+        L.check(self.lib.rihip_tower_backward_reduce2(
+            self.d, self.H, self.bws_u.data_ptr(), bu, 0, nu, g[ukeys[0]].data_ptr(), g[ukeys[1]].data_ptr(),
+            g[ukeys[2]].data_ptr(), g[ukeys[3]].data_ptr(), self.bws_i.data_ptr(), bi, 1, ni, g[ikeys[0]].data_ptr(),
+            g[ikeys[1]].data_ptr(), g[ikeys[2]].data_ptr(), g[ikeys[3]].data_ptr(), 0, self._st), "tower_backward_reduce2")
 
     def step(self, user_ids: torch.Tensor, item_ids: torch.Tensor, item_genres: torch.Tensor,
              lr: Optional[float] = None) -> torch.Tensor:
@@ -367,9 +377,12 @@ class HipBPRTrainer:
             self._fwd(self.utab, user_ids, None, ukeys, self.U, self.hidU, self.denU, s0)
 
         if self.loss_mode == "sampled":
+            # single GPU: the loss partials are summed by the clip-coefficient launch (one dependent launch less)
             L.check(lib.rihip_bpr_pair_loss(self.U.data_ptr(), self.I.data_ptr(), self.I[B:].data_ptr(), B, d,
-                                            self.loss.data_ptr(), self.dU.data_ptr(), self.dI.data_ptr(),
-                                            self.dI[B:].data_ptr(), self.lpart.data_ptr(), st), "bpr_pair_loss")
+                                            self.loss.data_ptr() if self.dist else None, self.dU.data_ptr(),
+                                            self.dI.data_ptr(), self.dI[B:].data_ptr(), self.lpart.data_ptr(), st),
+                    "bpr_pair_loss")
+            self._loss_fold = None if self.dist else (self.lpart.data_ptr(), lib.rihip_bpr_pair_nparts(B), 1.0 / B)
             if self.dist:  # mean over the global batch
                 self.dU.div_(self.world); self.dI.div_(self.world)
                 self.loss.div_(self.world)
@@ -397,6 +410,7 @@ class HipBPRTrainer:
             sideB.wait_event(self._ev_dxi)
             with torch.cuda.stream(sideB):
                 self.iopt.reduce(self.dXi, pp + 8 * o2, sideB.cuda_stream)
+        self._bwd_reduce(ukeys, ikeys)
 
         # ---- gradient exchange (multi-GPU) + global grad norm -> clip coef (device scalar)
         iid, dXi = item_ids, self.dXi
@@ -455,8 +469,10 @@ class HipBPRTrainer:
         if dense:   # one launch for the three squared norms (MLP, user table, item table gradients)
             L.check(lib.rihip_sumsq_multi(3, self._mt_g, self._mt_n, pp, st), "sumsq_multi")
         # clip coefficient + the step clock (Adam's bias-corrected step size of this step; counter advanced for the next)
+        lf = self._loss_fold
         L.check(lib.rihip_clip_coef_step(pp, n_part, self.max_norm, self.coef.data_ptr(), self.gnorm.data_ptr(),
-                                         *clock, st), "clip_coef_step")
+                                         *clock, lf[0] if lf else None, lf[1] if lf else 0, lf[2] if lf else 0.0,
+                                         self.loss.data_ptr(), st), "clip_coef_step")
         cp = self.coef.data_ptr()
         hp = self.hyper_dev.data_ptr()
         if dense:   # one Adam launch for MLP + both tables; it leaves the table gradients zeroed for the next scatter
@@ -466,12 +482,11 @@ class HipBPRTrainer:
         L.check(lib.rihip_adam_dense(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
                                      self.flat_v.data_ptr(), self.flat_p.numel(), lr, self.b1, self.b2, self.eps,
                                      self.wd, t, cp, hp, st), "adam_dense")
-        sideA.wait_stream(cur)   # clip coefficient + step clock are ready: the two tables update side by side
-        with torch.cuda.stream(sideA):
-            self.uopt.adam(lr, self.b1, self.b2, self.eps, self.wd, t, cp, sideA.cuda_stream, hp)
+        # both row-sparse Adam launches on the main stream: they are HBM-bound, side by side they take as long as one
+        # after the other, and the two stream joins cost more than the one kernel boundary
+        self.uopt.adam(lr, self.b1, self.b2, self.eps, self.wd, t, cp, st, hp)
         if self.iopt._B > 0:
             self.iopt.adam(lr, self.b1, self.b2, self.eps, self.wd, t, cp, st, hp)
-        cur.wait_stream(sideA)   # the next step's towers read the user table
         return self.loss
 
     def _fetch_item_rows(self, item_ids: torch.Tensor, st: int):
@@ -548,10 +563,13 @@ class HipBPRTrainer:
             self._sweep(0, self.I.data_ptr(), B, off, self.U_all.data_ptr(), G, 0, d,
                                             self.pos_all.data_ptr(), self.r_all.data_ptr(), G, self.dI.data_ptr(), None,
                                             None, self.sws.data_ptr(), self.inbatch_precision, st)
-        L.check(lib.rihip_sum_partials(self.lpart.data_ptr(), self.n_lparts, 1.0 / (G * (G - 1.0)),
-                                       self.loss.data_ptr(), st), "sum_partials")
         if self.dist:
+            L.check(lib.rihip_sum_partials(self.lpart.data_ptr(), self.n_lparts, 1.0 / (G * (G - 1.0)),
+                                           self.loss.data_ptr(), st), "sum_partials")
             all_reduce_sum_(self.loss, self.pg)
+            self._loss_fold = None
+        else:   # summed by the clip-coefficient launch
+            self._loss_fold = (self.lpart.data_ptr(), self.n_lparts, 1.0 / (G * (G - 1.0)))
 
 
 def cosine_lr(lr0: float, epoch: int, t_max: int) -> float:
