@@ -406,6 +406,23 @@ __global__ __launch_bounds__(512, 2) void tower_wgrad_kernel(TowerBwdArgs a, con
   f32x4 stg[NV];
   float stg_gen = 0.f;  // one genre value per thread (32 rows x 18 <= 576: threads 0..575? -> 2 passes below)
   float stg_gen2 = 0.f;
+  // the x rows are gathered by id: the ids of a tile are requested one tile earlier than its rows, so that no row load
+  // waits for its address inside the tile loop (an id -> row chain stalled every outstanding load of the step)
+  constexpr int NXV = (V_X + 511) / 512;   // float4 slots of the x part per thread (they are the last slots)
+  static_assert(V_G + 2 * V_H == (NV - NXV) * 512, "x part must start on a slot boundary");
+  int64_t xid[NXV];
+  auto load_ids = [&](int64_t tile) {
+    const int64_t row_base = tile * TROWS;
+#pragma unroll
+    for (int q = 0; q < NXV; ++q) {
+      const int j = tid + q * 512, r = j / (D / 4);
+      const int64_t g = row_base + r;
+      int64_t id = 0;
+      if (j < V_X && g < a.B) id = a.ids[g];
+      if (id < 0 || id >= a.n_rows) id = 0;
+      xid[q] = id;
+    }
+  };
   auto load_tile = [&](int64_t tile) {
     const int64_t row_base = tile * TROWS;
 #pragma unroll
@@ -427,11 +444,7 @@ __global__ __launch_bounds__(512, 2) void tower_wgrad_kernel(TowerBwdArgs a, con
       } else if (idx < V_G + 2 * V_H + V_X) {
         const int j = idx - V_G - 2 * V_H, r = j / (D / 4), c4 = j % (D / 4);
         const int64_t g = row_base + r;
-        if (g < a.B) {
-          int64_t id = a.ids[g];
-          if (id < 0 || id >= a.n_rows) id = 0;
-          v = reinterpret_cast<const f32x4*>(a.table + (size_t)id * D)[c4];
-        }
+        if (g < a.B) v = reinterpret_cast<const f32x4*>(a.table + (size_t)xid[i - (NV - NXV)] * D)[c4];
       }
       stg[i] = v;
     }
@@ -489,26 +502,43 @@ __global__ __launch_bounds__(512, 2) void tower_wgrad_kernel(TowerBwdArgs a, con
   const int64_t ntiles = (a.B + TROWS - 1) / TROWS;
   int64_t tile = blockIdx.x;
   if (tile < ntiles) {
+    load_ids(tile);
     load_tile(tile);
     store_tile(smem);
+    load_ids(tile + gridDim.x);   // (rows past the batch read id 0: never used)
   }
   __syncthreads();
   int cur = 0;
   for (; tile < ntiles; tile += gridDim.x, cur ^= 1) {
     const bool more = tile + gridDim.x < ntiles;
-    if (more) load_tile(tile + gridDim.x);
+    if (more) {
+      load_tile(tile + gridDim.x);
+      load_ids(tile + 2 * (int64_t)gridDim.x);
+    }
     const float* Gs = smem + cur * BUF;
     const float* Hs = Gs + TROWS * D;
     const float* Ps = Hs + TROWS * H;
     const float* Xs = Ps + TROWS * H;
     if (w < 4) {
       // dW2[d][hid] tiles (d-tile w, hidden tiles 0..3): A = gy columns, B = hid columns; k = row
-#pragma unroll 8
-      for (int s = 0; s < TROWS / 2; ++s) {
-        const int row = 2 * s + hh;
-        const float av = Gs[row * D + w * 32 + r31];
+      // operands of k-step s+1 are requested before the MFMAs of k-step s are issued (the compiler's own schedule
+      // waited for every LDS read right before the two MFMAs that use it)
+      float av[2], bv[2][4];
+      av[0] = Gs[hh * D + w * 32 + r31];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = mfma32(av, Hs[row * H + t * 32 + r31], acc[t]);
+      for (int t = 0; t < 4; ++t) bv[0][t] = Hs[hh * H + t * 32 + r31];
+#pragma unroll
+      for (int s = 0; s < TROWS / 2; ++s) {
+        const int c = s & 1, nrow = 2 * (s + 1) + hh;
+        if (s + 1 < TROWS / 2) {
+          av[c ^ 1] = Gs[nrow * D + w * 32 + r31];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) bv[c ^ 1][t] = Hs[nrow * H + t * 32 + r31];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = mfma32(av[c], bv[c][t], acc[t]);
+        __builtin_amdgcn_sched_barrier(0);
       }
       // column sums: threads 0..127 -> db2 (gy), 128..255 -> db1 (dPre)
       const float* src = (tid < D) ? Gs + tid : Ps + (tid - D);
@@ -519,12 +549,22 @@ __global__ __launch_bounds__(512, 2) void tower_wgrad_kernel(TowerBwdArgs a, con
       colsum += cs;
     } else {
       // dW1[hid][k] tiles (hidden tile w-4, x tiles 0..NX-1): A = dPre columns, B = x columns
-#pragma unroll 8
-      for (int s = 0; s < TROWS / 2; ++s) {
-        const int row = 2 * s + hh;
-        const float av = Ps[row * H + (w - 4) * 32 + r31];
+      float av[2], bv[2][NX];
+      av[0] = Ps[hh * H + (w - 4) * 32 + r31];
 #pragma unroll
-        for (int t = 0; t < NX; ++t) acc[t] = mfma32(av, Xs[row * XW + t * 32 + r31], acc[t]);
+      for (int t = 0; t < NX; ++t) bv[0][t] = Xs[hh * XW + t * 32 + r31];
+#pragma unroll
+      for (int s = 0; s < TROWS / 2; ++s) {
+        const int c = s & 1, nrow = 2 * (s + 1) + hh;
+        if (s + 1 < TROWS / 2) {
+          av[c ^ 1] = Ps[nrow * H + (w - 4) * 32 + r31];
+#pragma unroll
+          for (int t = 0; t < NX; ++t) bv[c ^ 1][t] = Xs[nrow * XW + t * 32 + r31];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NX; ++t) acc[t] = mfma32(av[c], bv[c][t], acc[t]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     if (more) store_tile(smem + (cur ^ 1) * BUF);
