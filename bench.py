@@ -512,19 +512,36 @@ def main():
                                                 "ms_per_step": alt["ms_per_step"], "roofline": alt["roofline"],
                                                 "config": alt["config"]}
         cfg = CONFIGS["cfg3"]        # secondary legs run on the cfg3 tables
-        sampled, model = leg_sampled(cfg, args, world, rank, dev, cpu_ok)
-        secondary["sampled_bpr"] = sampled
         n_users_local = cfg["users"] // world
+        model = idx = X = None
         if world == 1:
-            secondary.update(leg_ml1m(dev, cpu_ok))
-        retr, idx, X = leg_retrieval(model, cfg, n_users_local, args, world, rank, dev, cpu_ok)
-        secondary["retrieval"] = retr
-        if world == 1:
-            try:
-                secondary["serve"] = leg_serve(model, X, n_users_local, dev, cpu_ok)
-            except Exception as e:  # the serve leg must never take the headline down
-                secondary["serve"] = {"error": repr(e)}
-                log(f"[bench] serve leg failed: {e!r}")
+            # (a secondary leg must never take the headline down; with world > 1 every rank takes part in the legs'
+            # barriers, so there a failure is left to surface instead of hanging the other ranks)
+            def guarded(name, fn):
+                try:
+                    return fn()
+                except Exception as e:
+                    secondary[name] = {"error": repr(e)}
+                    log(f"[bench] {name} leg failed: {e!r}")
+                    return None
+            r = guarded("sampled_bpr", lambda: leg_sampled(cfg, args, world, rank, dev, cpu_ok))
+            if r is not None:
+                secondary["sampled_bpr"], model = r
+            r = guarded("ml1m", lambda: leg_ml1m(dev, cpu_ok))
+            if r is not None:
+                secondary.update(r)
+            if model is not None:
+                r = guarded("retrieval", lambda: leg_retrieval(model, cfg, n_users_local, args, world, rank, dev, cpu_ok))
+                if r is not None:
+                    secondary["retrieval"], idx, X = r
+                    r = guarded("serve", lambda: leg_serve(model, X, n_users_local, dev, cpu_ok))
+                    if r is not None:
+                        secondary["serve"] = r
+        else:
+            sampled, model = leg_sampled(cfg, args, world, rank, dev, cpu_ok)
+            secondary["sampled_bpr"] = sampled
+            retr, idx, X = leg_retrieval(model, cfg, n_users_local, args, world, rank, dev, cpu_ok)
+            secondary["retrieval"] = retr
         del model, idx, X
     cpu = None
     if cpu_ok:
