@@ -276,6 +276,10 @@ int rihip_ip_index_save(void* handle, const char* path);          /* host path; 
 int rihip_ip_index_load(const char* path, void** handle);         /* host path; synchronous */
 /* rows[i] = rows[i] >= 0 ? item_ids[rows[i]] : -1   (faiss_index.py:123, :148-152) */
 int rihip_map_rows_to_ids(int64_t* rows, int64_t n, const int64_t* item_ids, void* stream);
+/* The same mapping inside rihip_ip_index_search (no second pass over the result): with a non-NULL device array of
+ * >= ntotal item ids, out_rows receives item_ids[row] (-1 padding unchanged).  The array is not copied and must stay
+ * valid while searches run; NULL restores row numbers. */
+int rihip_ip_index_set_id_map(void* handle, const int64_t* item_ids_dev);
 
 /* ---- LambdaMART forward --------------------------------------------------------------------
  * Replaces lgb.Booster(model_file=...) (src/models/ranker.py:219) and Booster.predict

@@ -96,6 +96,7 @@ SIGNATURES = {
     "rihip_ip_index_save": (C.c_int, [vp, C.c_char_p]),
     "rihip_ip_index_load": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
     "rihip_map_rows_to_ids": (C.c_int, [vp, c_i64, vp, vp]),
+    "rihip_ip_index_set_id_map": (C.c_int, [vp, vp]),
     "rihip_gbdt_load_text": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
     "rihip_gbdt_create_from_text": (C.c_int, [C.c_char_p, c_i64, C.POINTER(vp)]),
     "rihip_gbdt_destroy": (C.c_int, [vp]),

@@ -36,6 +36,7 @@ struct IpIndex {
   __bf16* Xb = nullptr;  // bf16 copy of X for the filter pass (flat index, N > 4*SAMPLE)
   float max_norm = 0.f;  // max row 2-norm (error bound of the bf16 filter)
   int two_precision = 1; // 1: bf16 filter + exact f32 re-score; 0: all-f32 search
+  const int64_t* id_map = nullptr;   // optional device array: search results are id_map[row] instead of row (not owned)
   DevBuf<float> qnorm;
   // IVF
   int nlist = 0, nprobe = 1;

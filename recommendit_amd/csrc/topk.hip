@@ -603,6 +603,7 @@ struct FinArgs {
   float eps_scale;
   // IVF with a sampled threshold: fewer than k candidates is only acceptable when nothing was filtered (thr = -inf)
   const float* ivf_thr;
+  const int64_t* id_map;  // optional: out_rows[i] = id_map[row] (the wrapper's faiss index -> item id), or null
 };
 
 __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
@@ -725,10 +726,256 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
       const uint64_t key = sbuf[i];
       sc = ord2f((uint32_t)(key >> 32));
       row = (int64_t)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull));
+      if (a.id_map) row = a.id_map[row];
     }
     a.out_scores[oslot * a.k + i] = sc;
     a.out_rows[oslot * a.k + i] = row;
   }
+}
+
+// ---- fused refinement of the two-precision search (one workgroup per query, candidates in LDS) ------------------
+// segments -> LDS | k-th largest APPROXIMATE score (radix select) | exact f32 re-score of the candidates that can still
+// reach the top-k | top-k select + sort of the exact keys | completeness proof -> outputs.  Same selections and the same
+// arithmetic as compact_segments_kernel + finalize_kernel(mode 1) + rerank_kernel + finalize_kernel(mode 0), without
+// the three candidate-list round trips through HBM and three kernel boundaries.
+struct RefineArgs {
+  const uint64_t* seg; const int* seg_cnt; int nsplit, seg_cap;
+  int64_t cap;            // candidate slots per query of the global scratch list `cand`
+  int lds_slots;          // candidate slots in LDS; a longer list is refined in `cand` (same code, slower)
+  uint64_t* cand;         // [nq, cap]
+  const float* X; const float* Q; int64_t N; int k;
+  const float* thr;       // approximate-score threshold the filter used (completeness proof)
+  float eps_scale;
+  float* out_scores; int64_t* out_rows; int* fail_flags;
+  const int64_t* id_map;  // optional: out_rows[i] = id_map[row] (the wrapper's faiss index -> item id), or null
+};
+
+// k_sel-th largest of n unique keys (LDS or global); returns the prefix T with zero low bytes once every key left in
+// the chosen bucket is needed (#{key >= T} == k_sel).  All 256 threads call it; hist/s_bin/s_above are workgroup LDS.
+__device__ __forceinline__ uint64_t radix_select_256(const uint64_t* keys, int64_t n, int k_sel, unsigned* hist,
+                                                     unsigned* s_bin, unsigned* s_above) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  uint64_t prefix = 0, mask = 0;
+  unsigned need = (unsigned)k_sel;
+  for (int pass = 0; pass < 8; ++pass) {
+    const int shift = 56 - 8 * pass;
+    hist[tid] = 0;
+    __syncthreads();
+    for (int64_t i = tid; i < n; i += 256) {
+      const uint64_t key = keys[i];
+      if ((key & mask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {  // wave 0: suffix scan over bins 255..0, 4 bins per lane
+      const int b0 = 255 - 4 * lane;
+      const unsigned h0 = hist[b0], h1 = hist[b0 - 1], h2 = hist[b0 - 2], h3 = hist[b0 - 3];
+      const unsigned mine = h0 + h1 + h2 + h3;
+      unsigned incl = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+      }
+      const unsigned before = incl - mine;
+      if (before < need && need <= incl) {
+        unsigned c = before;
+        int b = b0;
+        if (c + h0 >= need) { b = b0; }
+        else { c += h0; if (c + h1 >= need) { b = b0 - 1; }
+        else { c += h1; if (c + h2 >= need) { b = b0 - 2; }
+        else { c += h2; b = b0 - 3; } } }
+        *s_bin = (unsigned)b;
+        *s_above = c;
+      }
+    }
+    __syncthreads();
+    need -= *s_above;
+    prefix |= (uint64_t)(*s_bin) << shift;
+    mask |= 0xFFull << shift;
+    const bool done = (hist[*s_bin] == need);
+    __syncthreads();
+    if (done) break;
+  }
+  return prefix;
+}
+
+// the part of refine_kernel after the candidate count is known; `ck` is the LDS list (address space inferred after
+// inlining: ds_* instructions) or the query's slice of the global scratch list
+template <int D>
+__device__ __forceinline__ void refine_body(const RefineArgs& a, uint64_t* ck, uint64_t* sbuf, const int n, const int* off,
+                                            unsigned* hist, unsigned& s_bin, unsigned& s_above, unsigned& s_cnt,
+                                            const float qn, const float (&qv)[D / 16], const int64_t q) {
+  constexpr int PER = D / 16;
+  const int tid = threadIdx.x, l16 = tid & 15, grp = tid >> 4;
+  for (int s = tid >> 6; s < a.nsplit; s += 4) {          // one wave per segment
+    const int cnt = off[s + 1] - off[s];
+    const uint64_t* src = a.seg + ((size_t)q * a.nsplit + s) * a.seg_cap;
+    for (int i = tid & 63; i < cnt; i += 64) ck[off[s] + i] = src[i];
+  }
+  __syncthreads();
+  // ---- k-th largest approximate score (a lower bound of it: the select stops early)
+  float kth = -INFINITY;
+  if (n >= a.k) kth = ord2f((uint32_t)(radix_select_256(ck, n, a.k, hist, &s_bin, &s_above) >> 32));
+  // At least k candidates have an approximate score >= kth, hence exact scores >= kth - eps, so the exact k-th score
+  // T* >= kth - eps; a candidate whose approximate score is below kth - 2 eps has an exact score < kth - eps <= T*: it
+  // cannot be in the top-k and its row is not fetched (key zeroed).
+  const float cut = kth - 2.f * a.eps_scale * qn - 1e-6f;
+  // four candidates per lane group and iteration: their row loads are in flight together
+  typedef float rowvec __attribute__((ext_vector_type(PER)));
+  for (int i0 = grp * 4; i0 < n; i0 += 64) {
+    uint32_t row[4];
+    bool go[4];
+    rowvec xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u;
+      const uint64_t key = i < n ? ck[i] : 0ull;
+      row[u] = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull);
+      go[u] = i < n && (int64_t)row[u] < a.N && !(ord2f((uint32_t)(key >> 32)) < cut);
+      if (go[u]) xv[u] = *reinterpret_cast<const rowvec*>(a.X + (size_t)row[u] * D + l16 * PER);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      uint64_t nk = 0ull;
+      if (go[u]) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) s = fmaf(qv[j], xv[u][j], s);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        nk = make_key(s, row[u]);
+      }
+      if (l16 == 0 && i0 + u < n) ck[i0 + u] = nk;
+    }
+  }
+  __syncthreads();
+  // ---- top-k of the exact keys, sorted
+  const int64_t need_min = a.k < a.N ? a.k : a.N;
+  bool fail = n < need_min;
+  int k_sel = a.k < n ? a.k : n;
+  uint64_t T = 0;
+  if (k_sel > 0) T = radix_select_256(ck, n, k_sel, hist, &s_bin, &s_above);
+  int P = 64;
+  while (P < k_sel) P <<= 1;
+  if (tid == 0) s_cnt = 0;
+  for (int i = tid; i < P; i += 256) sbuf[i] = 0ull;
+  __syncthreads();
+  if (k_sel > 0) {
+    for (int i = tid; i < n; i += 256) {
+      const uint64_t key = ck[i];
+      if (key > T) {
+        const unsigned pos = atomicAdd(&s_cnt, 1u);
+        if (pos < (unsigned)P) sbuf[pos] = key;
+      }
+    }
+  }
+  __syncthreads();
+  {  // keys are unique except the all-zero padding key: the remaining slots all equal T
+    const int cgt = (int)s_cnt;
+    for (int i = cgt + tid; i < k_sel; i += 256) sbuf[i] = T;
+  }
+  __syncthreads();
+  {  // exchanges at distance <= 64 stay inside the 128-key segment one wave owns: barrier only around the others
+    int prev = 128;
+    for (int size = 2; size <= P; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        if (stride >= 128 || prev >= 128) __syncthreads();
+        else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        prev = stride;
+        for (int i = tid; i < P / 2; i += 256) {
+          const int lo = (i / stride) * (stride << 1) + (i % stride);
+          const int hi = lo + stride;
+          const bool desc = ((lo & size) == 0);
+          const uint64_t x = sbuf[lo], y = sbuf[hi];
+          if (desc ? (x < y) : (x > y)) { sbuf[lo] = y; sbuf[hi] = x; }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (k_sel == a.k && k_sel > 0) {  // completeness proof of the approximate filter
+    const float sk = ord2f((uint32_t)(sbuf[k_sel - 1] >> 32));
+    if (sk < a.thr[q] + a.eps_scale * qn + 2e-6f) fail = true;
+  }
+  if (tid == 0) a.fail_flags[q] = fail ? 1 : 0;
+  for (int i = tid; i < a.k; i += 256) {
+    float sc = -INFINITY;
+    int64_t row = -1;
+    if (i < k_sel && sbuf[i] != 0ull) {
+      const uint64_t key = sbuf[i];
+      sc = ord2f((uint32_t)(key >> 32));
+      row = (int64_t)(0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull));
+      if (a.id_map) row = a.id_map[row];
+    }
+    a.out_scores[q * a.k + i] = sc;
+    a.out_rows[q * a.k + i] = row;
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t rbuf[];   // [cap] candidates | [P] sort buffer
+  __shared__ unsigned hist[256];
+  __shared__ int off[1025];
+  __shared__ unsigned s_bin, s_above, s_cnt;
+  __shared__ int s_over;
+  __shared__ float s_qn;
+  constexpr int PER = D / 16;
+  const int tid = threadIdx.x, l16 = tid & 15, grp = tid >> 4;
+  const int64_t q = blockIdx.x;
+  uint64_t* sbuf = rbuf + a.lds_slots;
+  {  // exclusive prefix of the (clamped) segment counts: 4 segments per thread, wave scan, 4 wave totals
+    int c[4], ov = 0, mine = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int sg = tid * 4 + u;
+      int v = sg < a.nsplit ? a.seg_cnt[q * a.nsplit + sg] : 0;
+      if (v > a.seg_cap) { ov = 1; v = a.seg_cap; }
+      c[u] = v; mine += v;
+    }
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if ((tid & 63) >= o) incl += t;
+    }
+    if ((tid & 63) == 63) hist[tid >> 6] = (unsigned)incl;
+    if (tid == 0) s_over = 0;
+    __syncthreads();
+    int base = incl - mine;
+    for (int w2 = 0; w2 < (tid >> 6); ++w2) base += (int)hist[w2];
+    if (ov) s_over = 1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int sg = tid * 4 + u;
+      if (sg <= a.nsplit) off[sg] = base;
+      base += c[u];
+    }
+    if (tid == 255) {   // base = the total here
+      off[a.nsplit] = base;
+      if (base > a.cap) s_over = 1;
+    }
+    __syncthreads();
+  }
+  float qv[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) qv[j] = a.Q[q * D + l16 * PER + j];
+  {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) s += qv[j] * qv[j];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (tid == 0) s_qn = sqrtf(s);
+  }
+  __syncthreads();
+  if (s_over) {   // a segment or the list overflowed: exact re-do of this query (outputs are overwritten by it)
+    if (tid == 0) a.fail_flags[q] = 1;
+    return;
+  }
+  const int n = off[a.nsplit];
+  if (n <= a.lds_slots) refine_body<D>(a, rbuf, sbuf, n, off, hist, s_bin, s_above, s_cnt, s_qn, qv, q);
+  else refine_body<D>(a, a.cand + (size_t)q * a.cap, sbuf, n, off, hist, s_bin, s_above, s_cnt, s_qn, qv, q);
 }
 
 __global__ void collect_fail_kernel(const int* __restrict__ flags, int64_t nq, int* list, int* n_fail) {
@@ -1106,7 +1353,7 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
   sa.X = h->X; sa.Q = Q; sa.nq = nq; sa.count = h->count.p;
   FinArgs fa;
   memset(&fa, 0, sizeof(fa));
-  fa.nq = nq; fa.k = k; fa.count = h->count.p; fa.out_scores = out_s; fa.out_rows = out_r;
+  fa.nq = nq; fa.k = k; fa.count = h->count.p; fa.out_scores = out_s; fa.out_rows = out_r; fa.id_map = h->id_map;
 
   if (h->ivf) {
     // population upper bound of one query = the nprobe longest lists (padded to the 64-row granule)
@@ -1185,7 +1432,7 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
       FinArgs f2;
       memset(&f2, 0, sizeof(f2));
       f2.nq = n; f2.k = k; f2.count = h->count.p; f2.out_scores = out_s; f2.out_rows = out_r; f2.cand = h->scand.p;
-      f2.cap = (int64_t)nprobe * k; f2.mode = 0; f2.out_slot = out_slot;
+      f2.cap = (int64_t)nprobe * k; f2.mode = 0; f2.out_slot = out_slot; f2.id_map = h->id_map;
       RCCHK(launch_finalize(f2, (unsigned)n, st));
       return check_launch("finalize");
     };
@@ -1322,29 +1569,57 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
   sa.n_virtual = h->N; sa.row_stride = 1; sa.thr = h->thr.p; sa.cand = h->cand.p; sa.cap = cap; sa.dense = 0;
   sa.cs = CSTRIDE; fa.count_stride = CSTRIDE;
   RCCHK(run_scan(sa, two_prec ? (h->N + TRB - 1) / TRB : n_tiles));
-  if (two_prec) {  // exact f32 re-score of the survivors (keys rewritten in place)
-    hipLaunchKernelGGL(compact_segments_kernel, dim3((unsigned)nq), dim3(256), 0, st, h->seg.p, h->seg_cnt.p, main_nsplit,
-                       seg_cap, h->cand.p, cap, h->count.p, CSTRIDE);
-    RCCHK(h->qnorm.reserve(nq));
-    RCCHK(h->thr2.reserve(nq));
-    {  // k-th largest APPROXIMATE score per query (a lower bound of it: the select stops early): rerank_kernel uses it
-       // to skip survivors that provably cannot reach the top-k -- about half of them
-      FinArgs f2 = fa;
-      f2.cand = h->cand.p; f2.cap = cap; f2.mode = 1; f2.rank = k; f2.thr_out = h->thr2.p; f2.fail_flags = nullptr;
-      f2.thr_chk = nullptr; f2.qnorm = nullptr; f2.ivf_thr = nullptr; f2.need_min = 0;
-      RCCHK(launch_finalize(f2, (unsigned)nq, st));
+  bool refined = false;
+  if (two_prec && k <= 2048) {
+    // one workgroup per query takes the survivors from the segments through approximate select, exact re-score,
+    // top-k select + sort and the completeness proof (refine_kernel)
+    RefineArgs r;
+    memset(&r, 0, sizeof(r));
+    r.seg = h->seg.p; r.seg_cnt = h->seg_cnt.p; r.nsplit = main_nsplit; r.seg_cap = seg_cap; r.cap = cap;
+    r.lds_slots = 2048; r.cand = h->cand.p; r.X = h->X; r.Q = Q; r.N = h->N; r.k = k; r.thr = h->thr.p;
+    r.eps_scale = (float)((1.0 / 256.0 + 1.0 / 262144.0) * (double)h->max_norm * 1.001);
+    r.out_scores = out_s; r.out_rows = out_r; r.fail_flags = h->fail_flags.p; r.id_map = h->id_map;
+    int P = 64;
+    while (P < k) P <<= 1;
+    const size_t lds = sizeof(uint64_t) * (size_t)(r.lds_slots + P);
+    static bool granted = false;
+    if (!granted) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(refine_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * (2048 + 2048));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(refine_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * (2048 + 2048));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(refine_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * (2048 + 2048));
+      granted = true;
     }
-    const float eps_sc = (float)((1.0 / 256.0 + 1.0 / 262144.0) * (double)h->max_norm * 1.001);
-    if (d == 32) hipLaunchKernelGGL((rerank_kernel<32>), dim3((unsigned)nq), dim3(256), 0, st, h->X, Q, h->cand.p, cap, h->count.p, h->qnorm.p, h->N, h->thr2.p, eps_sc, CSTRIDE);
-    else if (d == 64) hipLaunchKernelGGL((rerank_kernel<64>), dim3((unsigned)nq), dim3(256), 0, st, h->X, Q, h->cand.p, cap, h->count.p, h->qnorm.p, h->N, h->thr2.p, eps_sc, CSTRIDE);
-    else hipLaunchKernelGGL((rerank_kernel<128>), dim3((unsigned)nq), dim3(256), 0, st, h->X, Q, h->cand.p, cap, h->count.p, h->qnorm.p, h->N, h->thr2.p, eps_sc, CSTRIDE);
-    fa.thr_chk = h->thr.p; fa.qnorm = h->qnorm.p;
-    fa.eps_scale = (float)((1.0 / 256.0 + 1.0 / 262144.0) * (double)h->max_norm * 1.001);
+    if (d == 32) hipLaunchKernelGGL((refine_kernel<32>), dim3((unsigned)nq), dim3(256), lds, st, r);
+    else if (d == 64) hipLaunchKernelGGL((refine_kernel<64>), dim3((unsigned)nq), dim3(256), lds, st, r);
+    else hipLaunchKernelGGL((refine_kernel<128>), dim3((unsigned)nq), dim3(256), lds, st, r);
+    RCCHK(check_launch("refine"));
+    refined = true;
   }
-  // ---- pass 2: finalize + exactness flags
-  fa.cand = h->cand.p; fa.cap = cap; fa.mode = 0; fa.fail_flags = h->fail_flags.p;
-  fa.need_min = k < h->N ? k : h->N; fa.thr_out = nullptr;
-  RCCHK(launch_finalize(fa, (unsigned)nq, st));
+  if (!refined) {
+  if (two_prec) {  // exact f32 re-score of the survivors (keys rewritten in place)
+      hipLaunchKernelGGL(compact_segments_kernel, dim3((unsigned)nq), dim3(256), 0, st, h->seg.p, h->seg_cnt.p, main_nsplit,
+                         seg_cap, h->cand.p, cap, h->count.p, CSTRIDE);
+      RCCHK(h->qnorm.reserve(nq));
+      RCCHK(h->thr2.reserve(nq));
+      {  // k-th largest APPROXIMATE score per query (a lower bound of it: the select stops early): rerank_kernel uses it
+         // to skip survivors that provably cannot reach the top-k -- about half of them
+        FinArgs f2 = fa;
+        f2.cand = h->cand.p; f2.cap = cap; f2.mode = 1; f2.rank = k; f2.thr_out = h->thr2.p; f2.fail_flags = nullptr;
+        f2.thr_chk = nullptr; f2.qnorm = nullptr; f2.ivf_thr = nullptr; f2.need_min = 0;
+        RCCHK(launch_finalize(f2, (unsigned)nq, st));
+      }
+      const float eps_sc = (float)((1.0 / 256.0 + 1.0 / 262144.0) * (double)h->max_norm * 1.001);
+      if (d == 32) hipLaunchKernelGGL((rerank_kernel<32>), dim3((unsigned)nq), dim3(256), 0, st, h->X, Q, h->cand.p, cap, h->count.p, h->qnorm.p, h->N, h->thr2.p, eps_sc, CSTRIDE);
+      else if (d == 64) hipLaunchKernelGGL((rerank_kernel<64>), dim3((unsigned)nq), dim3(256), 0, st, h->X, Q, h->cand.p, cap, h->count.p, h->qnorm.p, h->N, h->thr2.p, eps_sc, CSTRIDE);
+      else hipLaunchKernelGGL((rerank_kernel<128>), dim3((unsigned)nq), dim3(256), 0, st, h->X, Q, h->cand.p, cap, h->count.p, h->qnorm.p, h->N, h->thr2.p, eps_sc, CSTRIDE);
+      fa.thr_chk = h->thr.p; fa.qnorm = h->qnorm.p;
+      fa.eps_scale = (float)((1.0 / 256.0 + 1.0 / 262144.0) * (double)h->max_norm * 1.001);
+    }
+    // ---- pass 2: finalize + exactness flags
+    fa.cand = h->cand.p; fa.cap = cap; fa.mode = 0; fa.fail_flags = h->fail_flags.p;
+    fa.need_min = k < h->N ? k : h->N; fa.thr_out = nullptr;
+    RCCHK(launch_finalize(fa, (unsigned)nq, st));
+  }
   hipLaunchKernelGGL(fill_int_kernel, dim3(1), dim3(64), 0, st, h->n_fail.p, 1, 0);
   hipLaunchKernelGGL(collect_fail_kernel, dim3(nqb), dim3(256), 0, st, h->fail_flags.p, nq, h->fail_list.p, h->n_fail.p);
   RCCHK(check_launch("finalize"));
@@ -1369,7 +1644,7 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
       FinArgs ff;
       memset(&ff, 0, sizeof(ff));
       ff.cand = h->fcand.p; ff.cap = h->N; ff.count = h->fcount.p; ff.nq = nfc; ff.k = k; ff.mode = 0;
-      ff.out_scores = out_s; ff.out_rows = out_r; ff.out_slot = h->fail_list.p + f0;
+      ff.out_scores = out_s; ff.out_rows = out_r; ff.out_slot = h->fail_list.p + f0; ff.id_map = h->id_map;
       RCCHK(launch_finalize(ff, (unsigned)nfc, st));
     }
     RCCHK(check_launch("fallback"));
@@ -1471,6 +1746,13 @@ extern "C" int rihip_ip_index_search(void* handle, const float* Q, int64_t nq, i
     int rc = search_chunk(h, Q + q0 * h->d, n, k, out_scores + q0 * k, out_rows + q0 * k, (hipStream_t)stream);
     if (rc) return rc;
   }
+  return RIHIP_OK;
+}
+
+extern "C" int rihip_ip_index_set_id_map(void* handle, const int64_t* item_ids_dev) {
+  IpIndex* h = (IpIndex*)handle;
+  RIHIP_REQUIRE(h, RIHIP_ERR_ARG, "ip_index_set_id_map: null handle");
+  h->id_map = item_ids_dev;   // not owned: must stay valid (>= ntotal entries) while searches run; NULL switches it off
   return RIHIP_OK;
 }
 

@@ -154,10 +154,13 @@ class FAISSIndex:
         return out
 
     # -- search (faiss_index.py:88-153) -------------------------------------------------------
-    def _search_device(self, q_dev: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
-        """q_dev: normalised f32 [nq,d] on device -> (scores [nq,k], rows [nq,k]) on device."""
+    def _search_device(self, q_dev: torch.Tensor, k: int, item_ids: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+        """q_dev: normalised f32 [nq,d] on device -> (scores [nq,k], rows [nq,k]) on device; item_ids=True: the rows
+        come back as item ids (faiss_index.py:123,148-152), mapped inside the search's last kernel."""
         lib = L.lib()
         nq = q_dev.shape[0]
+        L.check(lib.rihip_ip_index_set_id_map(self.index._h, self._item_ids_dev.data_ptr() if item_ids else None),
+                "ip_index_set_id_map")
         if k > int(lib.rihip_ip_index_max_k()):
             raise ValueError(f"k={k} exceeds the device select buffer ({int(lib.rihip_ip_index_max_k())}); "
                              "the reference (faiss) has no such limit -- see INTEGRATION.md")
@@ -191,9 +194,7 @@ class FAISSIndex:
         queries = queries / np.maximum(norms, 1e-8)
         k = min(k, self.index.ntotal)
         q_dev = torch.from_numpy(np.ascontiguousarray(queries)).to(L.device())
-        scores, rows = self._search_device(q_dev, k)
-        L.check(L.lib().rihip_map_rows_to_ids(rows.data_ptr(), rows.numel(), self._item_ids_dev.data_ptr(),
-                                              L.stream_ptr()), "map_rows_to_ids")
+        scores, rows = self._search_device(q_dev, k, item_ids=True)
         return scores.cpu().numpy(), rows.cpu().numpy()
 
     def batch_search_device(self, queries: torch.Tensor, k: int = 500, normalized: bool = False
@@ -206,10 +207,7 @@ class FAISSIndex:
         if not normalized:
             q = q / torch.clamp(torch.linalg.norm(q, dim=1, keepdim=True), min=1e-8)
         k = min(k, self.index.ntotal)
-        scores, rows = self._search_device(q, k)
-        L.check(L.lib().rihip_map_rows_to_ids(rows.data_ptr(), rows.numel(), self._item_ids_dev.data_ptr(),
-                                              L.stream_ptr()), "map_rows_to_ids")
-        return scores, rows
+        return self._search_device(q, k, item_ids=True)
 
     # -- persistence (faiss_index.py:159-205) -------------------------------------------------
     def save(self, path: str, format: str = "rihip") -> None:

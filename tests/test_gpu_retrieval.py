@@ -280,3 +280,31 @@ def test_ivf_large_lists_thresholded_path():
     ref_sc, ref_rows = R.topk_ip_exact(Q, X, k)
     recall = np.mean([len(set(rows5[q]) & set(ref_rows[q])) / k for q in range(nq)])
     assert recall > 0.3, recall
+
+
+@pytest.mark.parametrize("kind", ["flat_small", "flat_two_precision", "ivf"])
+def test_in_search_item_id_mapping_equals_the_separate_pass(kind):
+    """rihip_ip_index_set_id_map: the search's last kernel writes item ids (faiss_index.py:123,148-152) -- same result as
+    mapping the returned rows afterwards, -1 padding untouched, and switching the map off restores row numbers."""
+    from recommendit_amd import _lib as L
+    rng = np.random.default_rng(5)
+    N, d, nq, k = (3000, 64, 40, 500) if kind != "flat_two_precision" else (70000, 128, 50, 500)
+    X = rng.standard_normal((N, d)).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    ids = rng.permutation(10 * N)[:N].astype(np.int64) + 1
+    from recommendit_amd import FAISSIndex
+    idx = FAISSIndex(embed_dim=d, exact=(kind != "ivf"), n_lists=30, n_probe=2)
+    idx.build_ivf_index(X, ids)
+    Q = rng.standard_normal((nq, d)).astype(np.float32)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    qd = torch.from_numpy(Q).to(L.device())
+    s_rows, rows = idx._search_device(qd, k)
+    s_ids, mapped = idx._search_device(qd, k, item_ids=True)
+    rows, mapped = rows.cpu().numpy(), mapped.cpu().numpy()
+    assert np.array_equal(s_rows.cpu().numpy(), s_ids.cpu().numpy())
+    want = np.where(rows >= 0, ids[np.maximum(rows, 0)], -1)
+    assert np.array_equal(mapped, want)
+    if kind == "ivf":
+        assert (rows < 0).any()                                   # short results exist: the padding stayed -1
+    _, again = idx._search_device(qd, k)                          # map switched off again
+    assert np.array_equal(again.cpu().numpy(), rows)
