@@ -438,3 +438,87 @@ def test_inbatch_bf16x3_precision_mode(B, d):
     l0, dU0, dI0 = inbatch_loss_and_grads(t(U), t(I), precision=0)
     scale = dU0.abs().max().item()
     assert (dU1 - dU0).abs().max().item() < 2e-4 * scale
+
+
+@pytest.mark.parametrize("B,d,H", [(200, 64, 128), (3000, 32, 64), (50000, 128, 128)])
+def test_backward_in_two_halves_is_bitwise_the_single_call(B, d, H):
+    """rihip_tower_backward_partial (gradient kernels, slabs left in the workspace) + rihip_tower_backward_reduce2 (the
+    slabs of BOTH towers summed in one pair of launches) give bit-for-bit the gradients of two rihip_tower_backward
+    calls -- same sums, same order; B = 50 000 takes the two-kernel backward with 256 slabs (two reduce levels)."""
+    import ctypes as C
+    from recommendit_amd import _lib as L
+    lib, dev = L.lib(), L.device()
+    g = torch.Generator(device=dev); g.manual_seed(B)
+    n_rows = 5000
+    f32 = dict(dtype=torch.float32, device=dev)
+
+    def tower(item):
+        K1 = d + (18 if item else 0)
+        Bt = 2 * B if item else B
+        return dict(
+            item=item, B=Bt, table=torch.randn((n_rows, d), generator=g, **f32),
+            ids=torch.randint(1, n_rows, (Bt,), device=dev, generator=g),
+            genres=(torch.rand((Bt, 18), device=dev, generator=g) < 0.2).float() if item else None,
+            W1=torch.randn((H, K1), generator=g, **f32) * 0.1, W2=torch.randn((d, H), generator=g, **f32) * 0.1,
+            gout=torch.randn((Bt, d), generator=g, **f32), out=torch.randn((Bt, d), generator=g, **f32),
+            den=torch.rand((Bt,), generator=g, **f32) + 0.5, hid=torch.relu(torch.randn((Bt, H), generator=g, **f32)),
+            ws=torch.empty((lib.rihip_tower_backward_workspace_floats(Bt, d, H, 1 if item else 0),), **f32))
+
+    def grads(t):
+        K1 = d + (18 if t["item"] else 0)
+        return [torch.empty((H, K1), **f32), torch.empty((H,), **f32), torch.empty((d, H), **f32), torch.empty((d,), **f32)]
+
+    def common(t, dX):
+        return (t["table"].data_ptr(), n_rows, t["ids"].data_ptr(), L.ptr(t["genres"]), t["B"], d, H, t["W1"].data_ptr(),
+                t["W2"].data_ptr(), t["gout"].data_ptr(), t["out"].data_ptr(), t["den"].data_ptr(), t["hid"].data_ptr(),
+                1.25, dX.data_ptr())
+
+    tu, ti = tower(False), tower(True)
+    st = L.stream_ptr()
+    ref, dX_ref = [], []
+    for t_ in (tu, ti):
+        gr, dX = grads(t_), torch.empty((t_["B"], d), **f32)
+        L.check(lib.rihip_tower_backward(*common(t_, dX), *(x.data_ptr() for x in gr), 0, t_["ws"].data_ptr(), st), "bwd")
+        ref.append([x.clone() for x in gr]); dX_ref.append(dX.clone())
+    got, dX_got, ns = [grads(tu), grads(ti)], [], []
+    for t_ in (tu, ti):
+        dX = torch.empty((t_["B"], d), **f32)
+        n = C.c_int(0)
+        L.check(lib.rihip_tower_backward_partial(*common(t_, dX), t_["ws"].data_ptr(), st, None, C.byref(n)), "partial")
+        dX_got.append(dX); ns.append(n.value)
+    assert ns[0] > 0 and ns[1] > 0
+    L.check(lib.rihip_tower_backward_reduce2(d, H, tu["ws"].data_ptr(), tu["B"], 0, ns[0], *(x.data_ptr() for x in got[0]),
+                                             ti["ws"].data_ptr(), ti["B"], 1, ns[1], *(x.data_ptr() for x in got[1]), 0, st),
+            "reduce2")
+    for a_, b_ in zip(dX_ref + ref[0] + ref[1], dX_got + got[0] + got[1]):
+        assert torch.equal(a_, b_)
+
+
+def test_clip_coef_step_folds_loss_sum_and_step_clock():
+    """rihip_clip_coef_step = rihip_clip_coef + the Adam clock of rihip_adam_hyper_step (for the step that is running)
+    + the loss sum of rihip_sum_partials, in one launch."""
+    from recommendit_amd import _lib as L
+    lib, dev = L.lib(), L.device()
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    part = torch.rand((3000,), dtype=torch.float64, device=dev, generator=g)
+    lpart = torch.rand((700,), dtype=torch.float64, device=dev, generator=g)
+    f32 = dict(dtype=torch.float32, device=dev)
+    coef, norm, hyper, loss = (torch.zeros((1,), **f32), torch.zeros((1,), **f32), torch.zeros((2,), **f32),
+                               torch.zeros((1,), **f32))
+    step = torch.full((1,), 7, dtype=torch.int64, device=dev)
+    lr = torch.full((1,), 3e-3, **f32)
+    st = L.stream_ptr()
+    L.check(lib.rihip_clip_coef_step(part.data_ptr(), part.numel(), 1.0, coef.data_ptr(), norm.data_ptr(), step.data_ptr(),
+                                     lr.data_ptr(), 0.9, 0.999, hyper.data_ptr(), lpart.data_ptr(), lpart.numel(), 0.25,
+                                     loss.data_ptr(), st), "clip_coef_step")
+    tn = float(np.sqrt(part.sum().item()))
+    assert abs(norm.item() - tn) <= 1e-5 * tn and abs(coef.item() - min(1.0, 1.0 / (tn + 1e-6))) < 1e-6
+    assert int(step.item()) == 8                                      # advanced for the next step
+    b1, b2 = float(np.float32(0.9)), float(np.float32(0.999))        # the ABI takes the betas as C floats
+    assert abs(hyper[0].item() - 3e-3 / (1 - b1 ** 7)) < 1e-8 and abs(hyper[1].item() - np.sqrt(1 - b2 ** 7)) < 1e-7
+    assert abs(loss.item() - 0.25 * lpart.sum().item()) < 1e-4
+    # without loss partials the loss output is left alone
+    loss.fill_(-1.0)
+    L.check(lib.rihip_clip_coef_step(part.data_ptr(), part.numel(), 1.0, coef.data_ptr(), norm.data_ptr(), step.data_ptr(),
+                                     lr.data_ptr(), 0.9, 0.999, hyper.data_ptr(), None, 0, 0.0, loss.data_ptr(), st), "clip")
+    assert loss.item() == -1.0 and int(step.item()) == 9
