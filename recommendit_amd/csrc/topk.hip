@@ -1494,7 +1494,11 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
 
   // ---- pass 0: threshold from a strided sample
   const bool two_prec = h->two_precision && h->Xb != nullptr;
-  const int64_t stride = h->N / SAMPLE;
+  // the two-precision path samples twice as many rows: the threshold estimate tightens (expected survivors per query
+  // 2 200 -> 1 700 at k = 500, N = 1 M), which saves more in the filter's emission and in the re-score than the longer
+  // sample pass costs (measured 2.33 -> 2.16 ms per 4 096 queries; 3x, 4x the same, 6x slower again)
+  const int64_t n_sample = (int64_t)SAMPLE * (two_prec ? 2 : 1);
+  const int64_t stride = h->N / n_sample > 0 ? h->N / n_sample : 1;
   const int64_t S = (h->N + stride - 1) / stride;  // virtual rows i*stride < N
   const double m = (double)k * (double)S / (double)h->N;
   // rank of the sample score used as threshold; the two-precision filter needs a little more head-room because
@@ -1507,9 +1511,6 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
   RCCHK(h->scand.reserve(nq * S));
   RCCHK(h->cand.reserve(nq * cap));
   const unsigned qgrid_b = (unsigned)((nq + QBB - 1) / QBB);
-  // small ranks (k = 500: 36): the sample pass keeps SAMPLE_T scores per stream in registers instead of writing all
-  // S scores per query; for larger ranks the truncation would bite, so those keep the dense sample
-  const bool sample_top = two_prec && rank <= 8 * SAMPLE_T;
   int main_nsplit = 0;
   int seg_cap = 64;   // per (query, corpus split) segment: 4x the expected survivors, a power of two, set below
   auto bf16_nsplit = [&](int64_t tiles) -> int {
@@ -1525,6 +1526,12 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
     if ((int64_t)seg_cap > cap) seg_cap = (int)cap;
   }
   const int64_t sample_tiles = (S + (two_prec ? TRB : TRS) - 1) / (two_prec ? TRB : TRS);
+  // The sample pass keeps the SAMPLE_T best scores of every stream (query x corpus split x row half) in registers
+  // instead of writing all S scores per query.  The threshold is the rank-th best of their union: exact while no stream
+  // holds more than SAMPLE_T of the sample's top `rank` -- with rank <= streams * SAMPLE_T / 4 (mean <= 2 per stream) a
+  // stream overflows with probability ~2e-4, and an overflow only lowers the threshold (more survivors, same result).
+  // Larger ranks keep the dense sample.
+  const bool sample_top = two_prec && (int64_t)rank * 4 <= (int64_t)2 * bf16_nsplit(sample_tiles) * SAMPLE_T;
   const int64_t cap_s = sample_top ? (int64_t)2 * bf16_nsplit(sample_tiles) * SAMPLE_T : S;  // streams = 2 * nsplit
   auto run_scan = [&](const ScanArgs& args, int64_t tiles) -> int {
     ScanArgs x = args;
