@@ -303,6 +303,14 @@ __global__ __launch_bounds__(256, 3) void scan_bf16_kernel(ScanArgs a) {
       if (ok0) a.seg_cnt[(size_t)qr0 * a.nsplit + by] = 0;
       if (ok1) a.seg_cnt[(size_t)qr1 * a.nsplit + by] = 0;
     }
+    if (MODE == 2) {   // empty streams hold key 0 (below every score): no memset of the stream table needed
+      const int64_t slot = ((int64_t)by * 2 + hh) * SAMPLE_T;
+#pragma unroll
+      for (int i = 0; i < SAMPLE_T; ++i) {
+        if (ok0) a.cand[(size_t)qr0 * a.cap + slot + i] = 0ull;
+        if (ok1) a.cand[(size_t)qr1 * a.cap + slot + i] = 0ull;
+      }
+    }
     return;
   }
   if (!DENSE) {   // visible to the flush after the first stage barrier
@@ -604,6 +612,7 @@ struct FinArgs {
   // IVF with a sampled threshold: fewer than k candidates is only acceptable when nothing was filtered (thr = -inf)
   const float* ivf_thr;
   const int64_t* id_map;  // optional: out_rows[i] = id_map[row] (the wrapper's faiss index -> item id), or null
+  int* zero_me;           // optional: one int this launch resets (the failed-query counter of the kernels that follow)
 };
 
 __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
@@ -612,8 +621,9 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
   __shared__ unsigned s_bin, s_above, s_cnt;
   const int tid = threadIdx.x, lane = tid & 63;
   const int64_t qi = blockIdx.x;
+  if (a.zero_me && qi == 0 && tid == 0) *a.zero_me = 0;
   const int64_t q = a.qmap ? a.qmap[qi] : qi;
-  const int cnt_raw = a.count[q * (a.count_stride > 1 ? a.count_stride : 1)];
+  const int cnt_raw = a.count ? a.count[q * (a.count_stride > 1 ? a.count_stride : 1)] : (int)a.cap;   // null: full lists
   const int64_t n = cnt_raw < a.cap ? cnt_raw : a.cap;
   const uint64_t* keys = a.cand + (size_t)q * a.cap;
   const int64_t oslot = a.out_slot ? a.out_slot[qi] : qi;
@@ -747,6 +757,7 @@ struct RefineArgs {
   const float* thr;       // approximate-score threshold the filter used (completeness proof)
   float eps_scale;
   float* out_scores; int64_t* out_rows; int* fail_flags;
+  int* fail_list; int* n_fail;   // failed queries are appended here (n_fail zeroed by an earlier launch)
   const int64_t* id_map;  // optional: out_rows[i] = id_map[row] (the wrapper's faiss index -> item id), or null
 };
 
@@ -897,7 +908,10 @@ __device__ __forceinline__ void refine_body(const RefineArgs& a, uint64_t* ck, u
     const float sk = ord2f((uint32_t)(sbuf[k_sel - 1] >> 32));
     if (sk < a.thr[q] + a.eps_scale * qn + 2e-6f) fail = true;
   }
-  if (tid == 0) a.fail_flags[q] = fail ? 1 : 0;
+  if (tid == 0) {
+    a.fail_flags[q] = fail ? 1 : 0;
+    if (fail) a.fail_list[atomicAdd(a.n_fail, 1)] = (int)q;   // (order immaterial: every failed query is re-done on its own)
+  }
   for (int i = tid; i < a.k; i += 256) {
     float sc = -INFINITY;
     int64_t row = -1;
@@ -970,7 +984,10 @@ __global__ __launch_bounds__(256) void refine_kernel(RefineArgs a) {
   }
   __syncthreads();
   if (s_over) {   // a segment or the list overflowed: exact re-do of this query (outputs are overwritten by it)
-    if (tid == 0) a.fail_flags[q] = 1;
+    if (tid == 0) {
+      a.fail_flags[q] = 1;
+      a.fail_list[atomicAdd(a.n_fail, 1)] = (int)q;
+    }
     return;
   }
   const int n = off[a.nsplit];
@@ -1566,13 +1583,15 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
     return dispatch_scan(d, x, dim3(qgrid, x.nsplit), st);
   };
   sa.n_virtual = S; sa.row_stride = stride; sa.thr = nullptr; sa.cand = h->scand.p; sa.cap = cap_s; sa.dense = 1;
-  if (sample_top) HIPCHK(hipMemsetAsync(h->scand.p, 0, sizeof(uint64_t) * (size_t)(nq * cap_s), st));  // empty streams: key 0
-  RCCHK(run_scan(sa, sample_tiles));
-  hipLaunchKernelGGL(fill_int_kernel, dim3(nqb), dim3(256), 0, st, h->count.p, nq, (int)cap_s);
+  RCCHK(run_scan(sa, sample_tiles));   // (the register top-T sample writes every stream slot, empty streams as key 0)
   fa.cand = h->scand.p; fa.cap = cap_s; fa.mode = 1; fa.rank = rank; fa.thr_out = h->thr.p;
+  fa.count = nullptr;                  // dense sample lists: cap_s keys each
+  fa.zero_me = h->n_fail.p;            // (reset here: refine_kernel appends the failed queries itself)
   RCCHK(launch_finalize(fa, (unsigned)nq, st));
-  // ---- pass 1: thresholded scan (atomic append of the rare survivors)
-  hipLaunchKernelGGL(fill_int_kernel, dim3((unsigned)((nq * CSTRIDE + 255) / 256)), dim3(256), 0, st, h->count.p, nq * CSTRIDE, 0);
+  fa.count = h->count.p; fa.zero_me = nullptr;
+  // ---- pass 1: thresholded scan (survivors into per-(query, split) segments; the f32 scan appends through `count`)
+  if (!two_prec)
+    hipLaunchKernelGGL(fill_int_kernel, dim3((unsigned)((nq * CSTRIDE + 255) / 256)), dim3(256), 0, st, h->count.p, nq * CSTRIDE, 0);
   sa.n_virtual = h->N; sa.row_stride = 1; sa.thr = h->thr.p; sa.cand = h->cand.p; sa.cap = cap; sa.dense = 0;
   sa.cs = CSTRIDE; fa.count_stride = CSTRIDE;
   RCCHK(run_scan(sa, two_prec ? (h->N + TRB - 1) / TRB : n_tiles));
@@ -1586,6 +1605,7 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
     r.lds_slots = 2048; r.cand = h->cand.p; r.X = h->X; r.Q = Q; r.N = h->N; r.k = k; r.thr = h->thr.p;
     r.eps_scale = (float)((1.0 / 256.0 + 1.0 / 262144.0) * (double)h->max_norm * 1.001);
     r.out_scores = out_s; r.out_rows = out_r; r.fail_flags = h->fail_flags.p; r.id_map = h->id_map;
+    r.fail_list = h->fail_list.p; r.n_fail = h->n_fail.p;
     int P = 64;
     while (P < k) P <<= 1;
     const size_t lds = sizeof(uint64_t) * (size_t)(r.lds_slots + P);
@@ -1627,8 +1647,10 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
     fa.need_min = k < h->N ? k : h->N; fa.thr_out = nullptr;
     RCCHK(launch_finalize(fa, (unsigned)nq, st));
   }
-  hipLaunchKernelGGL(fill_int_kernel, dim3(1), dim3(64), 0, st, h->n_fail.p, 1, 0);
-  hipLaunchKernelGGL(collect_fail_kernel, dim3(nqb), dim3(256), 0, st, h->fail_flags.p, nq, h->fail_list.p, h->n_fail.p);
+  if (!refined) {
+    hipLaunchKernelGGL(fill_int_kernel, dim3(1), dim3(64), 0, st, h->n_fail.p, 1, 0);
+    hipLaunchKernelGGL(collect_fail_kernel, dim3(nqb), dim3(256), 0, st, h->fail_flags.p, nq, h->fail_list.p, h->n_fail.p);
+  }
   RCCHK(check_launch("finalize"));
   HIPCHK(hipMemcpyAsync(h->h_nfail, h->n_fail.p, sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
