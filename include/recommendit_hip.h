@@ -92,6 +92,26 @@ int rihip_tower_backward_reduce2(int d, int hidden, float* ws_a, int64_t B_a, in
                                  int n_slabs_b, float* dW1_b, float* db1_b, float* dW2_b, float* db2_b, int accumulate,
                                  void* stream);
 
+/* Both towers of one training step in one launch each way (a step of batch 256 is bounded by its ~10 dependent
+ * launches).  rihip_tower_io carries what differs per tower in rihip_tower_forward / rihip_tower_backward_partial;
+ * user->genres must be NULL and item->genres non-NULL.  Batches that take the chip-filling kernels (>= 49 152 rows)
+ * or arguments the pair kernels do not cover fall back to the two single calls -- the results are bit-identical either
+ * way.  The two towers need separate workspaces. */
+typedef struct rihip_tower_io {
+  const float* table; int64_t n_rows; const int64_t* ids; const float* genres; int64_t B;
+  const float *W1, *b1, *W2, *b2;
+  uint64_t seed; int64_t row0;
+  float *out, *hid, *denom;          /* forward outputs = backward inputs */
+  float* fwd_workspace;              /* rihip_tower_forward_workspace_floats, nullable */
+  const float* grad_out; float* dX;  /* backward */
+  float* bwd_workspace;              /* rihip_tower_backward_workspace_floats */
+} rihip_tower_io;
+int rihip_tower_forward_pair(const rihip_tower_io* user, const rihip_tower_io* item, int d, int hidden, int training,
+                             float dropout_p, int* err_flag, const int64_t* seed_step_dev, void* stream);
+int rihip_tower_backward_partial_pair(const rihip_tower_io* user, const rihip_tower_io* item, int d, int hidden,
+                                      float dropout_scale, void* stream, void* dx_event_user, void* dx_event_item,
+                                      int* n_slabs_user, int* n_slabs_item);
+
 /* nn.Embedding backward (dense): grad_table[ids[b]] += dX[b]; row 0 (padding_idx, two_tower.py:27,54) and ids outside
  * [1, n_rows) are skipped.  Bitwise reproducible: every row receives its samples one after the other in batch order,
  * starting from its current contents (the float32 chain of index_add_ on a CPU) -- no floating-point atomics.

@@ -65,6 +65,8 @@ SIGNATURES = {
     "rihip_bpr_pair_nparts": (c_i64, [c_i64]),
     "rihip_tower_backward_partial": (C.c_int, [vp, c_i64, vp, vp, c_i64, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp,
                                                C.c_float, vp, vp, vp, vp, vp]),
+    "rihip_tower_forward_pair": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp]),
+    "rihip_tower_backward_partial_pair": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp, vp, vp, vp, vp]),
     "rihip_tower_backward_reduce2": (C.c_int, [C.c_int, C.c_int, vp, c_i64, C.c_int, C.c_int, vp, vp, vp, vp, vp, c_i64,
                                                C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp]),
     "rihip_rows_workspace_bytes": (c_i64, [c_i64, C.c_int]),
@@ -141,6 +143,14 @@ class LambdamartParams(C.Structure):
                 ("label_gain", C.c_double * 32), ("learning_rate", C.c_double), ("reg_alpha", C.c_double),
                 ("reg_lambda", C.c_double), ("feature_fraction", C.c_double), ("min_sum_hessian", C.c_double),
                 ("sigmoid", C.c_double), ("seed", C.c_uint64)]
+
+
+class TowerIO(C.Structure):
+    """mirror of rihip_tower_io (include/recommendit_hip.h): one tower of a step for the *_pair entry points"""
+    _fields_ = [("table", C.c_void_p), ("n_rows", C.c_int64), ("ids", C.c_void_p), ("genres", C.c_void_p), ("B", C.c_int64),
+                ("W1", C.c_void_p), ("b1", C.c_void_p), ("W2", C.c_void_p), ("b2", C.c_void_p), ("seed", C.c_uint64),
+                ("row0", C.c_int64), ("out", C.c_void_p), ("hid", C.c_void_p), ("denom", C.c_void_p),
+                ("fwd_workspace", C.c_void_p), ("grad_out", C.c_void_p), ("dX", C.c_void_p), ("bwd_workspace", C.c_void_p)]
 
 
 class RihipError(RuntimeError):

@@ -99,6 +99,26 @@ __global__ void pack_frag_rows_kernel(const float* __restrict__ Wa, int Na, int 
 }
 
 
+struct PackDesc { const float* W; int N, K, KB; f32x4* Wp; int nb; };
+struct PackArgs { PackDesc m[4]; int n; };
+// the same packing for up to four matrices (both towers of a step) in one launch
+__global__ void pack_frag_rows_multi_kernel(PackArgs a) {
+  int b = blockIdx.x, t = 0;
+  while (t < a.n - 1 && b >= a.m[t].nb) { b -= a.m[t].nb; ++t; }
+  const PackDesc m = a.m[t];
+  const int i = b * blockDim.x + threadIdx.x;
+  if (i >= (m.N / 32) * m.KB * 64) return;
+  const int lane = i & 63, kb = (i >> 6) % m.KB, ct = (i >> 6) / m.KB;
+  const int row = ct * 32 + (lane & 31), h = lane >> 5;
+  f32x4 v;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int k = kb * 8 + 4 * h + s;
+    v[s] = (k < m.K) ? m.W[(size_t)row * m.K + k] : 0.f;
+  }
+  m.Wp[i] = v;
+}
+
 template <int D, int K1P, bool ITEM>
 __device__ __forceinline__ void gather_tile(float* Xs, int ldx, const float* __restrict__ table, int64_t n_rows,
                                             const int64_t* __restrict__ ids, const float* __restrict__ genres,
@@ -128,16 +148,17 @@ __device__ __forceinline__ void gather_tile(float* Xs, int ldx, const float* __r
   }
 }
 
+// body of the forward kernel; `block` of `nblocks` workgroups work on this tower (the pair kernel below runs the user
+// and the item tower of a small batch in ONE launch: a step of B = 256 is bounded by its dependent launches)
 template <int D, int H, bool ITEM>
-__global__ __launch_bounds__(256, 2) void tower_fwd_kernel(TowerFwdArgs a) {
+__device__ __forceinline__ void tower_fwd_body(const TowerFwdArgs& a, float* Xs, float* Hs, const int block,
+                                               const int nblocks) {
   constexpr int K1 = D + (ITEM ? 18 : 0);
   constexpr int K1P = (K1 + 7) / 8 * 8;
   constexpr int LDX = K1P + 4, LDH = H + 4, LDY = D + 4;
   constexpr int KB1 = K1P / 8, KB2 = H / 8;
   using T1 = WaveTiles<H>;
   using T2 = WaveTiles<D>;
-  __shared__ __attribute__((aligned(16))) float Xs[TM * LDX];  // X tile, later aliased by the Y tile
-  __shared__ __attribute__((aligned(16))) float Hs[TM * LDH];
   static_assert(LDY <= LDX, "Y tile must fit in the X tile");
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -159,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void tower_fwd_kernel(TowerFwdArgs a) {
   const uint32_t inner0 = rihip_lowbias32((uint32_t)(seed_mul >> 32) + 0x9E3779B9u);
 
   const int64_t ntiles = (a.B + TM - 1) / TM;
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int64_t tile = block; tile < ntiles; tile += nblocks) {
     const int64_t row_base = tile * TM;
     gather_tile<D, K1P, ITEM>(Xs, LDX, a.table, a.n_rows, a.ids, a.genres, row_base, a.B, tid, a.err_flag);
     __syncthreads();
@@ -242,12 +263,30 @@ __global__ __launch_bounds__(256, 2) void tower_fwd_kernel(TowerFwdArgs a) {
   }
 }
 
+template <int D, int H, bool ITEM>
+__global__ __launch_bounds__(256, 2) void tower_fwd_kernel(TowerFwdArgs a) {
+  constexpr int K1P = (D + (ITEM ? 18 : 0) + 7) / 8 * 8;
+  __shared__ __attribute__((aligned(16))) float Xs[TM * (K1P + 4)];  // X tile, later aliased by the Y tile
+  __shared__ __attribute__((aligned(16))) float Hs[TM * (H + 4)];
+  tower_fwd_body<D, H, ITEM>(a, Xs, Hs, (int)blockIdx.x, (int)gridDim.x);
+}
+// user tower on blocks [0, grid_u), item tower on the rest
+template <int D, int H>
+__global__ __launch_bounds__(256, 2) void tower_fwd_pair_kernel(TowerFwdArgs au, TowerFwdArgs ai, int grid_u) {
+  constexpr int K1P = (D + 18 + 7) / 8 * 8;
+  __shared__ __attribute__((aligned(16))) float Xs[TM * (K1P + 4)];
+  __shared__ __attribute__((aligned(16))) float Hs[TM * (H + 4)];
+  if ((int)blockIdx.x < grid_u) tower_fwd_body<D, H, false>(au, Xs, Hs, (int)blockIdx.x, grid_u);
+  else tower_fwd_body<D, H, true>(ai, Xs, Hs, (int)blockIdx.x - grid_u, (int)gridDim.x - grid_u);
+}
+
 // -----------------------------------------------------------------------------------------
 // Backward
 // -----------------------------------------------------------------------------------------
 
 template <int D, int H, bool ITEM>
-__global__ __launch_bounds__(256) void tower_bwd_kernel(TowerBwdArgs a) {
+__device__ __forceinline__ void tower_bwd_body(const TowerBwdArgs& a, float* Xs, float* Hs, float* Gs, const int block,
+                                               const int nblocks) {
   constexpr int K1 = D + (ITEM ? 18 : 0);
   constexpr int K1P = (K1 + 7) / 8 * 8;
   constexpr int LDX = K1P + 4, LDH = H + 4, LDG = D + 4;
@@ -261,10 +300,7 @@ __global__ __launch_bounds__(256) void tower_bwd_kernel(TowerBwdArgs a) {
   // CTH==2: wave w owns h-tile (w&1) and x-tiles (w>>1), (w>>1)+2, ...
   constexpr int TPW1 = (CTH == 4) ? NX : (NX + 1) / 2;
 
-  __shared__ __attribute__((aligned(16))) float Xs[TM * LDX + 32];  // +32: partial last x-tile over-read
-  __shared__ __attribute__((aligned(16))) float Hs[TM * LDH];       // hid tile, then dPre tile
-  __shared__ __attribute__((aligned(16))) float Gs[TM * LDG];       // gy tile
-
+  // Xs [TM * LDX + 32] (+32: partial last x-tile over-read) | Hs [TM * LDH] hid tile, then dPre tile | Gs [TM * LDG] gy tile
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r31 = lane & 31, hh = lane >> 5;
 
@@ -289,7 +325,7 @@ __global__ __launch_bounds__(256) void tower_bwd_kernel(TowerBwdArgs a) {
   constexpr int ctx1_step = (CTH == 4) ? 1 : 2;
 
   const int64_t ntiles = (a.B + TM - 1) / TM;
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int64_t tile = block; tile < ntiles; tile += nblocks) {
     const int64_t row_base = tile * TM;
     // ---- stage: gy (normalise backward), hid, gathered x
     {
@@ -413,7 +449,7 @@ __global__ __launch_bounds__(256) void tower_bwd_kernel(TowerBwdArgs a) {
 
   // ---- write this workgroup's partial weight grads: slab = [dW1 (H*K1) | db1 (H) | dW2 (D*H) | db2 (D)]
   constexpr int P = H * K1 + H + D * H + D;
-  float* sl = a.slab + (size_t)blockIdx.x * P;
+  float* sl = a.slab + (size_t)block * P;
 #pragma unroll
   for (int t = 0; t < TPW1; ++t) {
     const int ctx = ctx1_0 + t * ctx1_step;
@@ -439,6 +475,25 @@ __global__ __launch_bounds__(256) void tower_bwd_kernel(TowerBwdArgs a) {
     }
   }
   if (tid < D) sl[H * K1 + H + D * H + tid] = ab2;
+}
+
+template <int D, int H, bool ITEM>
+__global__ __launch_bounds__(256) void tower_bwd_kernel(TowerBwdArgs a) {
+  constexpr int K1P = (D + (ITEM ? 18 : 0) + 7) / 8 * 8;
+  __shared__ __attribute__((aligned(16))) float Xs[TM * (K1P + 4) + 32];
+  __shared__ __attribute__((aligned(16))) float Hs[TM * (H + 4)];
+  __shared__ __attribute__((aligned(16))) float Gs[TM * (D + 4)];
+  tower_bwd_body<D, H, ITEM>(a, Xs, Hs, Gs, (int)blockIdx.x, (int)gridDim.x);
+}
+// user tower on blocks [0, grid_u), item tower on the rest (each writes the slabs of its own workspace)
+template <int D, int H>
+__global__ __launch_bounds__(256) void tower_bwd_pair_kernel(TowerBwdArgs au, TowerBwdArgs ai, int grid_u) {
+  constexpr int K1P = (D + 18 + 7) / 8 * 8;
+  __shared__ __attribute__((aligned(16))) float Xs[TM * (K1P + 4) + 32];
+  __shared__ __attribute__((aligned(16))) float Hs[TM * (H + 4)];
+  __shared__ __attribute__((aligned(16))) float Gs[TM * (D + 4)];
+  if ((int)blockIdx.x < grid_u) tower_bwd_body<D, H, false>(au, Xs, Hs, Gs, (int)blockIdx.x, grid_u);
+  else tower_bwd_body<D, H, true>(ai, Xs, Hs, Gs, (int)blockIdx.x - grid_u, (int)gridDim.x - grid_u);
 }
 
 // grads (+)= sum over slabs, two levels, fixed order => deterministic
@@ -617,6 +672,17 @@ template <int D, int H>
 int launch_bwd(bool item, const TowerBwdArgs& a, int grid, hipStream_t st) {
   if (item) hipLaunchKernelGGL((tower_bwd_kernel<D, H, true>), dim3(grid), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((tower_bwd_kernel<D, H, false>), dim3(grid), dim3(256), 0, st, a);
+  return 0;
+}
+
+template <int D, int H>
+int launch_fwd_pair(const TowerFwdArgs& au, const TowerFwdArgs& ai, int grid_u, int grid_i, hipStream_t st) {
+  hipLaunchKernelGGL((tower_fwd_pair_kernel<D, H>), dim3(grid_u + grid_i), dim3(256), 0, st, au, ai, grid_u);
+  return 0;
+}
+template <int D, int H>
+int launch_bwd_pair(const TowerBwdArgs& au, const TowerBwdArgs& ai, int grid_u, int grid_i, hipStream_t st) {
+  hipLaunchKernelGGL((tower_bwd_pair_kernel<D, H>), dim3(grid_u + grid_i), dim3(256), 0, st, au, ai, grid_u);
   return 0;
 }
 
@@ -837,6 +903,112 @@ extern "C" int rihip_tower_backward(const float* table, int64_t n_rows, const in
                                     int accumulate, float* workspace, void* stream) {
   return rihip_tower_backward_ev(table, n_rows, ids, genres, B, d, hidden, W1, W2, grad_out, out, denom, hid, dropout_scale,
                                  dX, dW1, db1, dW2, db2, accumulate, workspace, stream, nullptr);
+}
+
+// ---- both towers of one step in one launch (small batches: a step of B = 256 is ~10 dependent launches of ~10 us) ----
+extern "C" int rihip_tower_forward_pair(const rihip_tower_io* user, const rihip_tower_io* item, int d, int hidden,
+                                        int training, float dropout_p, int* err_flag, const int64_t* seed_step_dev,
+                                        void* stream) {
+  RIHIP_REQUIRE(user && item, RIHIP_ERR_ARG, "tower_forward_pair: null pointer");
+  RIHIP_REQUIRE(rihip_tower_supported(d, hidden), RIHIP_ERR_SHAPE,
+                "tower_forward: unsupported (embed_dim=%d, hidden_dim=%d)", d, hidden);
+  const rihip_tower_io* io[2] = {user, item};
+  const char* ev = getenv("RIHIP_TOWER_FWD");
+  bool pair = user->B > 0 && item->B > 0 && user->B < 49152 && item->B < 49152 && !(ev && atoi(ev) == 3) &&
+              user->genres == nullptr && item->genres != nullptr && dropout_p >= 0.f && dropout_p < 1.f;
+  for (int t = 0; t < 2 && pair; ++t)
+    pair = io[t]->table && io[t]->ids && io[t]->W1 && io[t]->b1 && io[t]->W2 && io[t]->b2 && io[t]->out &&
+           io[t]->n_rows > 0 && aligned16(io[t]->table) && aligned16(io[t]->out) && (!io[t]->hid || aligned16(io[t]->hid)) &&
+           (!io[t]->fwd_workspace || aligned16(io[t]->fwd_workspace));
+  if (!pair) {   // anything unusual (or a chip-filling batch): the two single calls, with their own checks
+    for (int t = 0; t < 2; ++t) {
+      const int rc = rihip_tower_forward(io[t]->table, io[t]->n_rows, io[t]->ids, io[t]->genres, io[t]->B, d, hidden,
+                                         io[t]->W1, io[t]->b1, io[t]->W2, io[t]->b2, training, dropout_p, io[t]->seed,
+                                         io[t]->row0, io[t]->out, io[t]->hid, io[t]->denom, err_flag, io[t]->fwd_workspace,
+                                         seed_step_dev, stream);
+      if (rc != RIHIP_OK) return rc;
+    }
+    return RIHIP_OK;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  TowerFwdArgs a[2];
+  int grid[2];
+  PackArgs pk;
+  pk.n = 0;
+  for (int t = 0; t < 2; ++t) {
+    const rihip_tower_io& o = *io[t];
+    a[t].table = o.table; a[t].n_rows = o.n_rows; a[t].ids = o.ids; a[t].genres = o.genres; a[t].B = o.B;
+    a[t].W1 = o.W1; a[t].b1 = o.b1; a[t].W2 = o.W2; a[t].b2 = o.b2; a[t].out = o.out; a[t].hid = o.hid; a[t].denom = o.denom;
+    a[t].training = (training && dropout_p > 0.f) ? 1 : 0;
+    a[t].seed_mul = rihip_seed_mul(o.seed); a[t].thresh24 = rihip_thresh24(dropout_p);
+    a[t].scale = 1.f / (1.f - dropout_p); a[t].row0 = o.row0; a[t].err_flag = err_flag; a[t].seed_step = seed_step_dev;
+    a[t].W1p = nullptr; a[t].W2p = nullptr;
+    const int64_t ntiles = (o.B + TM - 1) / TM;
+    grid[t] = (int)(ntiles < 2 * RIHIP_NCU ? ntiles : 2 * RIHIP_NCU);
+    if (o.fwd_workspace && ntiles > 64) {   // same rule as rihip_tower_forward: fragment-major weights for many workgroups
+      const int K1 = d + (t ? 18 : 0), KB1 = (K1 + 7) / 8, KB2 = hidden / 8;
+      f32x4* w1p = reinterpret_cast<f32x4*>(o.fwd_workspace);
+      f32x4* w2p = w1p + (size_t)(hidden / 32) * KB1 * 64;
+      const int n1 = (hidden / 32) * KB1 * 64, n2 = (d / 32) * KB2 * 64;
+      pk.m[pk.n++] = PackDesc{o.W1, hidden, K1, KB1, w1p, (n1 + 255) / 256};
+      pk.m[pk.n++] = PackDesc{o.W2, d, hidden, KB2, w2p, (n2 + 255) / 256};
+      a[t].W1p = w1p; a[t].W2p = w2p;
+    }
+  }
+  if (pk.n > 0) {
+    int nb = 0;
+    for (int i = 0; i < pk.n; ++i) nb += pk.m[i].nb;
+    for (int i = pk.n; i < 4; ++i) pk.m[i] = pk.m[0];
+    hipLaunchKernelGGL(pack_frag_rows_multi_kernel, dim3(nb), dim3(256), 0, st, pk);
+  }
+  DISPATCH_DH(launch_fwd_pair, a[0], a[1], grid[0], grid[1], st)
+  RIHIP_CHECK_LAUNCH();
+  return RIHIP_OK;
+}
+
+extern "C" int rihip_tower_backward_partial_pair(const rihip_tower_io* user, const rihip_tower_io* item, int d, int hidden,
+                                                 float dropout_scale, void* stream, void* dx_event_user,
+                                                 void* dx_event_item, int* n_slabs_user, int* n_slabs_item) {
+  RIHIP_REQUIRE(user && item && n_slabs_user && n_slabs_item, RIHIP_ERR_ARG, "tower_backward_partial_pair: null pointer");
+  RIHIP_REQUIRE(rihip_tower_supported(d, hidden), RIHIP_ERR_SHAPE,
+                "tower_backward: unsupported (embed_dim=%d, hidden_dim=%d)", d, hidden);
+  const rihip_tower_io* io[2] = {user, item};
+  int* ns[2] = {n_slabs_user, n_slabs_item};
+  void* evs[2] = {dx_event_user, dx_event_item};
+  const char* ev = getenv("RIHIP_TOWER_BWD");
+  bool pair = user->B > 0 && item->B > 0 && user->B < 49152 && item->B < 49152 && !(ev && atoi(ev) == 3) &&
+              user->genres == nullptr && item->genres != nullptr;
+  for (int t = 0; t < 2 && pair; ++t)
+    pair = io[t]->table && io[t]->ids && io[t]->W1 && io[t]->W2 && io[t]->grad_out && io[t]->out && io[t]->denom &&
+           io[t]->hid && io[t]->dX && io[t]->bwd_workspace && aligned16(io[t]->table) && aligned16(io[t]->grad_out) &&
+           aligned16(io[t]->out) && aligned16(io[t]->hid);
+  pair = pair && user->bwd_workspace != item->bwd_workspace;
+  if (!pair) {
+    for (int t = 0; t < 2; ++t) {
+      const int rc = rihip_tower_backward_partial(io[t]->table, io[t]->n_rows, io[t]->ids, io[t]->genres, io[t]->B, d, hidden,
+                                                  io[t]->W1, io[t]->W2, io[t]->grad_out, io[t]->out, io[t]->denom, io[t]->hid,
+                                                  dropout_scale, io[t]->dX, io[t]->bwd_workspace, stream, evs[t], ns[t]);
+      if (rc != RIHIP_OK) return rc;
+    }
+    return RIHIP_OK;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  TowerBwdArgs a[2];
+  int grid[2];
+  for (int t = 0; t < 2; ++t) {
+    const rihip_tower_io& o = *io[t];
+    a[t].table = o.table; a[t].n_rows = o.n_rows; a[t].ids = o.ids; a[t].genres = o.genres; a[t].B = o.B; a[t].W1 = o.W1;
+    a[t].W2 = o.W2; a[t].gout = o.grad_out; a[t].out = o.out; a[t].denom = o.denom; a[t].hid = o.hid;
+    a[t].scale = dropout_scale; a[t].dX = o.dX; a[t].slab = o.bwd_workspace;
+    const int64_t ntiles = (o.B + TM - 1) / TM;
+    grid[t] = (int)(ntiles < RIHIP_NCU ? ntiles : RIHIP_NCU);
+    *ns[t] = grid[t];
+  }
+  DISPATCH_DH(launch_bwd_pair, a[0], a[1], grid[0], grid[1], st)
+  RIHIP_CHECK_LAUNCH();
+  for (int t = 0; t < 2; ++t)
+    if (evs[t]) (void)hipEventRecord((hipEvent_t)evs[t], st);
+  return RIHIP_OK;
 }
 
 namespace {

@@ -210,6 +210,7 @@ class HipBPRTrainer:
         self.bws_u = torch.empty((self.lib.rihip_tower_backward_workspace_floats(B, d, H, 0),), **f32)
         self.bws_i = torch.empty((self.lib.rihip_tower_backward_workspace_floats(nI, d, H, 1),), **f32)
         self._nslab = [(0, 0), (0, 0)]
+        self._tio = None
         self.fws_u = torch.empty((self.lib.rihip_tower_forward_workspace_floats(d, H, 0),), **f32)
         self.fws_i = torch.empty((self.lib.rihip_tower_forward_workspace_floats(d, H, 1),), **f32)
         self.np_mlp = self.lib.rihip_sumsq_nparts()
@@ -267,6 +268,29 @@ class HipBPRTrainer:
                                              out.data_ptr(), hid.data_ptr(), den.data_ptr(), self.err.data_ptr(),
                                              (self.fws_u if genres is None else self.fws_i).data_ptr(),
                                              self.step_dev.data_ptr(), self._st), "tower_forward")
+
+    def _tower_io(self, ukeys, ikeys, user_ids, item_ids, item_genres, s0):
+        """the two rihip_tower_io blocks of this step (single GPU, item table on this GPU)"""
+        if self._tio is None:
+            self._tio = (L.TowerIO(), L.TowerIO())
+        for io, (tab, keys, ids, gen, out, hid, den, fws, gout, dX, bws, seed) in zip(self._tio, (
+                (self.utab, ukeys, user_ids, None, self.U, self.hidU, self.denU, self.fws_u, self.dU, self.dXu, self.bws_u, s0),
+                (self.itab, ikeys, item_ids, item_genres, self.I, self.hidI, self.denI, self.fws_i, self.dI, self.dXi,
+                 self.bws_i, s0 + 1))):
+            io.table, io.n_rows, io.ids, io.genres, io.B = tab.data_ptr(), tab.shape[0], ids.data_ptr(), L.ptr(gen), ids.numel()
+            io.W1, io.b1, io.W2, io.b2 = (self.pv[k].data_ptr() for k in keys)
+            io.seed, io.row0 = seed, 0
+            io.out, io.hid, io.denom, io.fwd_workspace = out.data_ptr(), hid.data_ptr(), den.data_ptr(), fws.data_ptr()
+            io.grad_out, io.dX, io.bwd_workspace = gout.data_ptr(), dX.data_ptr(), bws.data_ptr()
+        return self._tio
+
+    @staticmethod
+    def _ev_handle(ev):
+        if ev is None:
+            return None
+        if not ev.cuda_event:      # the handle only exists after a first record
+            ev.record(torch.cuda.current_stream())
+        return ev.cuda_event
 
     def _bwd(self, table, ids, genres, keys, gout, out, den, hid, dX, dx_event=None):
         """dx_event: a torch.cuda.Event that is recorded on the launch stream as soon as dX is complete (before the
@@ -371,10 +395,17 @@ class HipBPRTrainer:
                 self._I_work = all_gather_into(self.I_all, self.I, self.pg, async_op=True)
         else:
             # item tower first: in the multi-GPU in-batch mode its outputs travel (all-gather) under the user tower
-            self._fwd(self.itab, item_ids, item_genres, ikeys, self.I, self.hidI, self.denI, s0 + 1)
-            if self.dist and self.loss_mode == "inbatch":
-                self._I_work = all_gather_into(self.I_all, self.I, self.pg, async_op=True)
-            self._fwd(self.utab, user_ids, None, ukeys, self.U, self.hidU, self.denU, s0)
+            if not self.dist:   # both towers in one launch (small batches; large ones take the two chip-filling kernels)
+                tio = self._tower_io(ukeys, ikeys, user_ids, item_ids, item_genres, s0)
+                training = self.model.training and self.p_drop > 0
+                L.check(lib.rihip_tower_forward_pair(C.byref(tio[0]), C.byref(tio[1]), d, self.H, 1 if training else 0,
+                                                     self.p_drop, self.err.data_ptr(), self.step_dev.data_ptr(), st),
+                        "tower_forward_pair")
+            else:
+                self._fwd(self.itab, item_ids, item_genres, ikeys, self.I, self.hidI, self.denI, s0 + 1)
+                if self.loss_mode == "inbatch":
+                    self._I_work = all_gather_into(self.I_all, self.I, self.pg, async_op=True)
+                self._fwd(self.utab, user_ids, None, ukeys, self.U, self.hidU, self.denU, s0)
 
         if self.loss_mode == "sampled":
             # single GPU: the loss partials are summed by the clip-coefficient launch (one dependent launch less)
@@ -390,13 +421,22 @@ class HipBPRTrainer:
         else:
             self._inbatch(st)
 
-        early_group_user()
-        # user tower first: in the multi-GPU stored-G form dI is still being reduce-scattered
-        self._bwd(self.utab, user_ids, None, ukeys, self.dU, self.U, self.denU, self.hidU, self.dXu,
-                  dx_event=self._ev_dxu if sparse else None)
         pp = self.part.data_ptr()
         o1 = self.np_mlp
         o2 = o1 + self.np_rows
+        pair_bwd = not self.dist and not sparse   # dense tables = the small-batch regime: both towers in one launch
+        if pair_bwd:
+            tio = self._tower_io(ukeys, ikeys, user_ids, item_ids, item_genres, s0)
+            scale = 1.0 / (1.0 - self.p_drop) if (self.model.training and self.p_drop > 0) else 1.0
+            nu, ni = C.c_int(0), C.c_int(0)
+            L.check(lib.rihip_tower_backward_partial_pair(C.byref(tio[0]), C.byref(tio[1]), d, self.H, scale, st, None, None,
+                                                          C.byref(nu), C.byref(ni)), "tower_backward_partial_pair")
+            self._nslab = [(nu.value, user_ids.numel()), (ni.value, item_ids.numel())]
+        early_group_user()
+        # user tower first: in the multi-GPU stored-G form dI is still being reduce-scattered
+        if not pair_bwd:
+            self._bwd(self.utab, user_ids, None, ukeys, self.dU, self.U, self.denU, self.hidU, self.dXu,
+                      dx_event=self._ev_dxu if sparse else None)
         if sparse:   # the user rows' segment sums start as soon as dXu exists: beside the user tower's weight gradients
             sideA.wait_event(self._ev_dxu)
             with torch.cuda.stream(sideA):
@@ -404,8 +444,9 @@ class HipBPRTrainer:
         early_group_item()
         if self._dI_work is not None:
             self._dI_work.wait(); self._dI_work = None
-        self._bwd(itab, iids, item_genres, ikeys, self.dI, self.I, self.denI, self.hidI, self.dXi,
-                  dx_event=self._ev_dxi if early_item_group else None)
+        if not pair_bwd:
+            self._bwd(itab, iids, item_genres, ikeys, self.dI, self.I, self.denI, self.hidI, self.dXi,
+                      dx_event=self._ev_dxi if early_item_group else None)
         if early_item_group:   # ... and the item rows' beside the item tower's weight gradients
             sideB.wait_event(self._ev_dxi)
             with torch.cuda.stream(sideB):
