@@ -522,3 +522,70 @@ def test_clip_coef_step_folds_loss_sum_and_step_clock():
     L.check(lib.rihip_clip_coef_step(part.data_ptr(), part.numel(), 1.0, coef.data_ptr(), norm.data_ptr(), step.data_ptr(),
                                      lr.data_ptr(), 0.9, 0.999, hyper.data_ptr(), None, 0, 0.0, loss.data_ptr(), st), "clip")
     assert loss.item() == -1.0 and int(step.item()) == 9
+
+
+@pytest.mark.parametrize("B,d,H", [(300, 64, 128), (5000, 32, 64), (70, 128, 128)])
+def test_pair_launches_are_bitwise_the_single_tower_calls(B, d, H):
+    """rihip_tower_forward_pair / rihip_tower_backward_partial_pair (user + item tower of a step in one launch; B = 5000
+    also packs the four weight matrices in one launch) against the single-tower entry points: identical bits."""
+    import ctypes as C
+    from recommendit_amd import _lib as L
+    lib, dev = L.lib(), L.device()
+    g = torch.Generator(device=dev); g.manual_seed(B + d)
+    f32 = dict(dtype=torch.float32, device=dev)
+    n_rows, p_drop = 4000, 0.2
+    step = torch.full((1,), 5, dtype=torch.int64, device=dev)
+    err = torch.zeros((1,), dtype=torch.int32, device=dev)
+
+    def tower(item):
+        K1, Bt = d + (18 if item else 0), (2 * B if item else B)
+        t_ = dict(item=item, B=Bt, table=torch.randn((n_rows, d), generator=g, **f32),
+                  ids=torch.randint(1, n_rows, (Bt,), device=dev, generator=g),
+                  genres=(torch.rand((Bt, 18), device=dev, generator=g) < 0.2).float() if item else None,
+                  W1=torch.randn((H, K1), generator=g, **f32) * 0.1, b1=torch.randn((H,), generator=g, **f32) * 0.1,
+                  W2=torch.randn((d, H), generator=g, **f32) * 0.1, b2=torch.randn((d,), generator=g, **f32) * 0.1,
+                  gout=torch.randn((Bt, d), generator=g, **f32), seed=11 + item)
+        for tag in ("a", "b"):   # a = single calls, b = pair calls
+            t_[tag] = dict(out=torch.empty((Bt, d), **f32), hid=torch.empty((Bt, H), **f32), den=torch.empty((Bt,), **f32),
+                           dX=torch.empty((Bt, d), **f32),
+                           fws=torch.empty((lib.rihip_tower_forward_workspace_floats(d, H, int(item)),), **f32),
+                           bws=torch.empty((lib.rihip_tower_backward_workspace_floats(Bt, d, H, int(item)),), **f32))
+        return t_
+
+    tu, ti = tower(False), tower(True)
+    st = L.stream_ptr()
+    nsl = {}
+    for t_ in (tu, ti):
+        o = t_["a"]
+        L.check(lib.rihip_tower_forward(t_["table"].data_ptr(), n_rows, t_["ids"].data_ptr(), L.ptr(t_["genres"]), t_["B"], d, H,
+                                        t_["W1"].data_ptr(), t_["b1"].data_ptr(), t_["W2"].data_ptr(), t_["b2"].data_ptr(), 1,
+                                        p_drop, t_["seed"], 0, o["out"].data_ptr(), o["hid"].data_ptr(), o["den"].data_ptr(),
+                                        err.data_ptr(), o["fws"].data_ptr(), step.data_ptr(), st), "fwd")
+        n = C.c_int(0)
+        L.check(lib.rihip_tower_backward_partial(t_["table"].data_ptr(), n_rows, t_["ids"].data_ptr(), L.ptr(t_["genres"]),
+                                                 t_["B"], d, H, t_["W1"].data_ptr(), t_["W2"].data_ptr(), t_["gout"].data_ptr(),
+                                                 o["out"].data_ptr(), o["den"].data_ptr(), o["hid"].data_ptr(), 1.25,
+                                                 o["dX"].data_ptr(), o["bws"].data_ptr(), st, None, C.byref(n)), "bwd")
+        nsl[t_["item"]] = n.value
+    ios = []
+    for t_ in (tu, ti):
+        o, io = t_["b"], L.TowerIO()
+        io.table, io.n_rows, io.ids, io.genres, io.B = t_["table"].data_ptr(), n_rows, t_["ids"].data_ptr(), L.ptr(t_["genres"]), t_["B"]
+        io.W1, io.b1, io.W2, io.b2 = t_["W1"].data_ptr(), t_["b1"].data_ptr(), t_["W2"].data_ptr(), t_["b2"].data_ptr()
+        io.seed, io.row0 = t_["seed"], 0
+        io.out, io.hid, io.denom, io.fwd_workspace = o["out"].data_ptr(), o["hid"].data_ptr(), o["den"].data_ptr(), o["fws"].data_ptr()
+        io.grad_out, io.dX, io.bwd_workspace = t_["gout"].data_ptr(), o["dX"].data_ptr(), o["bws"].data_ptr()
+        ios.append(io)
+    L.check(lib.rihip_tower_forward_pair(C.byref(ios[0]), C.byref(ios[1]), d, H, 1, p_drop, err.data_ptr(), step.data_ptr(), st),
+            "fwd_pair")
+    nu, ni = C.c_int(0), C.c_int(0)
+    L.check(lib.rihip_tower_backward_partial_pair(C.byref(ios[0]), C.byref(ios[1]), d, H, 1.25, st, None, None, C.byref(nu),
+                                                  C.byref(ni)), "bwd_pair")
+    assert (nu.value, ni.value) == (nsl[False], nsl[True])
+    for t_, ns in ((tu, nu.value), (ti, ni.value)):
+        for key in ("out", "hid", "den", "dX"):
+            assert torch.equal(t_["a"][key], t_["b"][key]), key
+        K1 = d + (18 if t_["item"] else 0)
+        P = H * K1 + H + d * H + d
+        assert torch.equal(t_["a"]["bws"][: ns * P], t_["b"]["bws"][: ns * P])      # the weight-gradient slabs
+    assert int(err.item()) == 0
