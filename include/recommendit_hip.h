@@ -121,6 +121,15 @@ int rihip_embedding_scatter_add(float* grad_table, int64_t n_rows, const int64_t
 int rihip_embedding_scatter_add2(float* grad_a, int64_t n_rows_a, const int64_t* ids_a, const float* dX_a, int64_t B_a,
                                  float* grad_b, int64_t n_rows_b, const int64_t* ids_b, const float* dX_b,
                                  int64_t B_b, int d, void* stream);
+/* rihip_tower_backward_reduce2 and rihip_embedding_scatter_add2 together: both wait only for the tower backward, so
+ * the scatter launch carries one slab-reduction level in extra workgroups (a dense small-batch step saves a dependent
+ * launch).  Results are bit-identical to the two separate calls.  Bs_* = samples scattered into each table. */
+int rihip_backward_reduce2_scatter2(int d, int hidden, float* ws_a, int64_t B_a, int item_a, int n_slabs_a, float* dW1_a,
+                                    float* db1_a, float* dW2_a, float* db2_a, float* ws_b, int64_t B_b, int item_b,
+                                    int n_slabs_b, float* dW1_b, float* db1_b, float* dW2_b, float* db2_b, int accumulate,
+                                    float* grad_a, int64_t n_rows_a, const int64_t* ids_a, const float* dX_a, int64_t Bs_a,
+                                    float* grad_b, int64_t n_rows_b, const int64_t* ids_b, const float* dX_b, int64_t Bs_b,
+                                    void* stream);
 
 /* ---- losses --------------------------------------------------------------------------------
  * rihip_bpr_pair_loss replaces TwoTowerModel.bpr_loss (two_tower.py:117-130) and its backward:

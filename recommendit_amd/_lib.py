@@ -65,6 +65,9 @@ SIGNATURES = {
     "rihip_bpr_pair_nparts": (c_i64, [c_i64]),
     "rihip_tower_backward_partial": (C.c_int, [vp, c_i64, vp, vp, c_i64, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp,
                                                C.c_float, vp, vp, vp, vp, vp]),
+    "rihip_backward_reduce2_scatter2": (C.c_int, [C.c_int, C.c_int, vp, c_i64, C.c_int, C.c_int, vp, vp, vp, vp, vp, c_i64,
+                                                  C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp, c_i64, vp, vp, c_i64, vp,
+                                                  c_i64, vp, vp, c_i64, vp]),
     "rihip_tower_forward_pair": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp]),
     "rihip_tower_backward_partial_pair": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp, vp, vp, vp, vp]),
     "rihip_tower_backward_reduce2": (C.c_int, [C.c_int, C.c_int, vp, c_i64, C.c_int, C.c_int, vp, vp, vp, vp, vp, c_i64,

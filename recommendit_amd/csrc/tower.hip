@@ -527,9 +527,47 @@ __device__ __forceinline__ int scat_run_end(const uint32_t* keys, int i, int m, 
   return lo_;
 }
 
+struct SlabDesc { const float* slab; float* part; int nslab, P, K1; float *dW1, *db1, *dW2, *db2; };
+struct SlabArgs { SlabDesc t[2]; int H, D, accumulate, nt; };
+// one element of a slab-reduction level for every tower of `a` (the arithmetic of slab_reduce1/2_multi_kernel): used by
+// the scatter kernel's extra workgroups -- scatter-add and slab reduction both wait only for the tower backward, so a
+// small-batch step runs them in one launch
+__device__ __forceinline__ void slab_level_element(const SlabArgs& a, int level, int64_t e) {
+  for (int z = 0; z < a.nt; ++z) {
+    const SlabDesc& t = a.t[z];
+    const int G = t.nslab < SLAB_GROUPS ? t.nslab : SLAB_GROUPS;
+    if (level == 1) {
+      if (t.nslab <= SLAB_GROUPS || e >= (int64_t)t.P * G) continue;
+      const int g = (int)(e / t.P), i = (int)(e % t.P);
+      float s = 0.f;
+      for (int k = g; k < t.nslab; k += G) s += t.slab[(size_t)k * t.P + i];
+      t.part[(size_t)g * t.P + i] = s;
+    } else {
+      if (e >= t.P) continue;
+      const int i = (int)e;
+      const float* part = t.nslab > SLAB_GROUPS ? t.part : t.slab;
+      float s = 0.f;
+      for (int g = 0; g < G; ++g) s += part[(size_t)g * t.P + i];
+      const int H = a.H, D = a.D, K1 = t.K1;
+      float* dst;
+      int off;
+      if (i < H * K1) { dst = t.dW1; off = i; }
+      else if (i < H * K1 + H) { dst = t.db1; off = i - H * K1; }
+      else if (i < H * K1 + H + D * H) { dst = t.dW2; off = i - H * K1 - H; }
+      else { dst = t.db2; off = i - H * K1 - H - D * H; }
+      dst[off] = a.accumulate ? dst[off] + s : s;
+    }
+  }
+}
+
 template <int LPR>   // lanes per row (float4 each); 0 = generic width, one lane per (run, column)
-__global__ __launch_bounds__(1024) void scatter_range_kernel(ScatterArgs a) {
+__global__ __launch_bounds__(1024) void scatter_range_kernel(ScatterArgs a, SlabArgs sl, int slab_level) {
   extern __shared__ uint32_t skeys[];
+  if ((int)blockIdx.x >= a.nwg) {   // extra workgroups (grid row 0 only): a slab-reduction level beside the scatter
+    if (blockIdx.y == 0 && slab_level > 0)
+      slab_level_element(sl, slab_level, (int64_t)((int)blockIdx.x - a.nwg) * 1024 + threadIdx.x);
+    return;
+  }
   __shared__ int wave_cnt[2][16];
   __shared__ int long_list[SCAT_CHUNK / SCAT_LONG + 1];
   __shared__ int n_long;
@@ -773,8 +811,6 @@ extern "C" int64_t rihip_tower_backward_workspace_floats(int64_t B, int d, int h
 }
 
 namespace {
-struct SlabDesc { const float* slab; float* part; int nslab, P, K1; float *dW1, *db1, *dW2, *db2; };
-struct SlabArgs { SlabDesc t[2]; int H, D, accumulate; };
 // the two levels of slab_reduce1/2_kernel for up to two towers per launch (blockIdx.z picks the tower)
 __global__ void slab_reduce1_multi_kernel(SlabArgs a) {
   const SlabDesc& t = a.t[blockIdx.z];
@@ -852,32 +888,45 @@ extern "C" int rihip_tower_backward_partial(const float* table, int64_t n_rows, 
   return RIHIP_OK;
 }
 
-extern "C" int rihip_tower_backward_reduce2(int d, int hidden, float* ws_a, int64_t B_a, int item_a, int n_slabs_a,
-                                            float* dW1_a, float* db1_a, float* dW2_a, float* db2_a, float* ws_b,
-                                            int64_t B_b, int item_b, int n_slabs_b, float* dW1_b, float* db1_b,
-                                            float* dW2_b, float* db2_b, int accumulate, void* stream) {
+namespace {
+// descriptors of the slab reduction of one or two towers; Pmax / nmax = largest slab size / slab count among them
+int slab_args(int d, int hidden, float* ws_a, int64_t B_a, int item_a, int n_slabs_a, float* dW1_a, float* db1_a,
+              float* dW2_a, float* db2_a, float* ws_b, int64_t B_b, int item_b, int n_slabs_b, float* dW1_b, float* db1_b,
+              float* dW2_b, float* db2_b, int accumulate, SlabArgs* out, int* Pmax, int* nmax) {
   RIHIP_REQUIRE(ws_a && dW1_a && db1_a && dW2_a && db2_a && n_slabs_a > 0 && B_a > 0, RIHIP_ERR_ARG,
                 "tower_backward_reduce2: bad arguments (tower a)");
   const bool two = ws_b != nullptr && n_slabs_b > 0;
   RIHIP_REQUIRE(!two || (dW1_b && db1_b && dW2_b && db2_b && B_b > 0 && ws_b != ws_a), RIHIP_ERR_ARG,
                 "tower_backward_reduce2: bad arguments (tower b)");
-  SlabArgs a;
-  a.H = hidden; a.D = d; a.accumulate = accumulate;
+  SlabArgs& a = *out;
+  a.H = hidden; a.D = d; a.accumulate = accumulate; a.nt = two ? 2 : 1;
   const int K1a = d + (item_a ? 18 : 0), Pa = hidden * K1a + hidden + d * hidden + d;
   a.t[0] = SlabDesc{ws_a, slab_part_of(ws_a, B_a, Pa), n_slabs_a, Pa, K1a, dW1_a, db1_a, dW2_a, db2_a};
   a.t[1] = a.t[0];
-  int Pmax = Pa, nmax = n_slabs_a;
+  *Pmax = Pa; *nmax = n_slabs_a;
   if (two) {
     const int K1b = d + (item_b ? 18 : 0), Pb = hidden * K1b + hidden + d * hidden + d;
     a.t[1] = SlabDesc{ws_b, slab_part_of(ws_b, B_b, Pb), n_slabs_b, Pb, K1b, dW1_b, db1_b, dW2_b, db2_b};
-    Pmax = Pb > Pmax ? Pb : Pmax;
-    nmax = n_slabs_b > nmax ? n_slabs_b : nmax;
+    *Pmax = Pb > *Pmax ? Pb : *Pmax;
+    *nmax = n_slabs_b > *nmax ? n_slabs_b : *nmax;
   }
+  return RIHIP_OK;
+}
+}  // namespace
+
+extern "C" int rihip_tower_backward_reduce2(int d, int hidden, float* ws_a, int64_t B_a, int item_a, int n_slabs_a,
+                                            float* dW1_a, float* db1_a, float* dW2_a, float* db2_a, float* ws_b,
+                                            int64_t B_b, int item_b, int n_slabs_b, float* dW1_b, float* db1_b,
+                                            float* dW2_b, float* db2_b, int accumulate, void* stream) {
+  SlabArgs a;
+  int Pmax = 0, nmax = 0;
+  const int rc = slab_args(d, hidden, ws_a, B_a, item_a, n_slabs_a, dW1_a, db1_a, dW2_a, db2_a, ws_b, B_b, item_b, n_slabs_b,
+                           dW1_b, db1_b, dW2_b, db2_b, accumulate, &a, &Pmax, &nmax);
+  if (rc != RIHIP_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
-  const unsigned nt = two ? 2 : 1;
   if (nmax > SLAB_GROUPS)
-    hipLaunchKernelGGL(slab_reduce1_multi_kernel, dim3((Pmax + 255) / 256, SLAB_GROUPS, nt), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(slab_reduce2_multi_kernel, dim3((Pmax + 255) / 256, 1, nt), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(slab_reduce1_multi_kernel, dim3((Pmax + 255) / 256, SLAB_GROUPS, a.nt), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(slab_reduce2_multi_kernel, dim3((Pmax + 255) / 256, 1, a.nt), dim3(256), 0, st, a);
   RIHIP_CHECK_LAUNCH();
   return RIHIP_OK;
 }
@@ -1012,7 +1061,8 @@ extern "C" int rihip_tower_backward_partial_pair(const rihip_tower_io* user, con
 }
 
 namespace {
-int scatter_launch(ScatterArgs a, int n_tables, hipStream_t st) {
+int scatter_launch(ScatterArgs a, int n_tables, hipStream_t st, const SlabArgs* slab = nullptr, int slab_level = 0,
+                   int slab_blocks = 0) {
   int64_t maxB = 0;
   int nwg = 4;
   bool al = a.D == 32 || a.D == 64 || a.D == 128;
@@ -1033,7 +1083,9 @@ int scatter_launch(ScatterArgs a, int n_tables, hipStream_t st) {
   const int64_t cap = maxB < SCAT_CHUNK ? maxB : SCAT_CHUNK;
   while (np2 < cap) np2 <<= 1;
   const size_t lds = (size_t)np2 * 4;
-  const dim3 grid((unsigned)nwg, (unsigned)n_tables);
+  SlabArgs sl = SlabArgs();
+  if (slab) sl = *slab;
+  const dim3 grid((unsigned)(nwg + (slab ? slab_blocks : 0)), (unsigned)n_tables);
   static bool granted = false;
   if (!granted) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scatter_range_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, SCAT_CHUNK * 4);
@@ -1042,10 +1094,11 @@ int scatter_launch(ScatterArgs a, int n_tables, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(scatter_range_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, SCAT_CHUNK * 4);
     granted = true;
   }
-  if (al && a.D == 128) hipLaunchKernelGGL((scatter_range_kernel<32>), grid, dim3(1024), lds, st, a);
-  else if (al && a.D == 64) hipLaunchKernelGGL((scatter_range_kernel<16>), grid, dim3(1024), lds, st, a);
-  else if (al && a.D == 32) hipLaunchKernelGGL((scatter_range_kernel<8>), grid, dim3(1024), lds, st, a);
-  else hipLaunchKernelGGL((scatter_range_kernel<0>), grid, dim3(1024), lds, st, a);
+  const int lvl = slab ? slab_level : 0;
+  if (al && a.D == 128) hipLaunchKernelGGL((scatter_range_kernel<32>), grid, dim3(1024), lds, st, a, sl, lvl);
+  else if (al && a.D == 64) hipLaunchKernelGGL((scatter_range_kernel<16>), grid, dim3(1024), lds, st, a, sl, lvl);
+  else if (al && a.D == 32) hipLaunchKernelGGL((scatter_range_kernel<8>), grid, dim3(1024), lds, st, a, sl, lvl);
+  else hipLaunchKernelGGL((scatter_range_kernel<0>), grid, dim3(1024), lds, st, a, sl, lvl);
   RIHIP_CHECK_LAUNCH();
   return RIHIP_OK;
 }
@@ -1074,4 +1127,35 @@ extern "C" int rihip_embedding_scatter_add2(float* grad_a, int64_t n_rows_a, con
   a.t[0] = ScatterDesc{grad_a, n_rows_a, ids_a, dX_a, B_a > 0 ? B_a : 0};
   a.t[1] = ScatterDesc{grad_b, n_rows_b, ids_b, dX_b, B_b > 0 ? B_b : 0};
   return scatter_launch(a, 2, (hipStream_t)stream);
+}
+
+// weight-gradient slab reduction of both towers AND the dense embedding scatter-add of both tables: both wait only for the
+// tower backward, so the scatter launch carries one reduction level in extra workgroups (the first level when there are
+// more than 16 slabs, followed by the second as its own launch; else the only level)
+extern "C" int rihip_backward_reduce2_scatter2(int d, int hidden, float* ws_a, int64_t B_a, int item_a, int n_slabs_a,
+                                               float* dW1_a, float* db1_a, float* dW2_a, float* db2_a, float* ws_b,
+                                               int64_t B_b, int item_b, int n_slabs_b, float* dW1_b, float* db1_b,
+                                               float* dW2_b, float* db2_b, int accumulate, float* grad_a,
+                                               int64_t n_rows_a, const int64_t* ids_a, const float* dX_a, int64_t Bs_a,
+                                               float* grad_b, int64_t n_rows_b, const int64_t* ids_b, const float* dX_b,
+                                               int64_t Bs_b, void* stream) {
+  RIHIP_REQUIRE(grad_a && ids_a && dX_a && grad_b && ids_b && dX_b && d > 0 && grad_a != grad_b && Bs_a > 0 && Bs_b > 0,
+                RIHIP_ERR_ARG, "backward_reduce2_scatter2: bad scatter arguments");
+  SlabArgs sl;
+  int Pmax = 0, nmax = 0;
+  const int rc = slab_args(d, hidden, ws_a, B_a, item_a, n_slabs_a, dW1_a, db1_a, dW2_a, db2_a, ws_b, B_b, item_b, n_slabs_b,
+                           dW1_b, db1_b, dW2_b, db2_b, accumulate, &sl, &Pmax, &nmax);
+  if (rc != RIHIP_OK) return rc;
+  ScatterArgs a;
+  a.D = d;
+  a.t[0] = ScatterDesc{grad_a, n_rows_a, ids_a, dX_a, Bs_a};
+  a.t[1] = ScatterDesc{grad_b, n_rows_b, ids_b, dX_b, Bs_b};
+  hipStream_t st = (hipStream_t)stream;
+  const bool two_levels = nmax > SLAB_GROUPS;
+  const int64_t elems = two_levels ? (int64_t)Pmax * SLAB_GROUPS : Pmax;
+  const int rc2 = scatter_launch(a, 2, st, &sl, two_levels ? 1 : 2, (int)((elems + 1023) / 1024));
+  if (rc2 != RIHIP_OK) return rc2;
+  if (two_levels) hipLaunchKernelGGL(slab_reduce2_multi_kernel, dim3((Pmax + 255) / 256, 1, sl.nt), dim3(256), 0, st, sl);
+  RIHIP_CHECK_LAUNCH();
+  return RIHIP_OK;
 }

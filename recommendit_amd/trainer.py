@@ -451,7 +451,9 @@ class HipBPRTrainer:
             sideB.wait_event(self._ev_dxi)
             with torch.cuda.stream(sideB):
                 self.iopt.reduce(self.dXi, pp + 8 * o2, sideB.cuda_stream)
-        self._bwd_reduce(ukeys, ikeys)
+        fuse_scatter = self.table_opt == "dense" and not self.dist   # (dense tables are single-GPU)
+        if not fuse_scatter:
+            self._bwd_reduce(ukeys, ikeys)
 
         # ---- gradient exchange (multi-GPU) + global grad norm -> clip coef (device scalar)
         iid, dXi = item_ids, self.dXi
@@ -490,11 +492,18 @@ class HipBPRTrainer:
             cur.wait_stream(sideA)
         else:
             # dense tables (ML-1M scale): the table gradients were zeroed by the previous step's Adam launch
-            uo, io = self.uopt, self.iopt   # both tables in one launch
-            L.check(lib.rihip_embedding_scatter_add2(
+            # both tables in one launch, which also carries the weight-gradient slab reduction of both towers (both wait
+            # only for the tower backward)
+            uo, io = self.uopt, self.iopt
+            (nu, bu), (ni, bi) = self._nslab
+            g = self.gv
+            L.check(lib.rihip_backward_reduce2_scatter2(
+                d, self.H, self.bws_u.data_ptr(), bu, 0, nu, g[ukeys[0]].data_ptr(), g[ukeys[1]].data_ptr(),
+                g[ukeys[2]].data_ptr(), g[ukeys[3]].data_ptr(), self.bws_i.data_ptr(), bi, 1, ni, g[ikeys[0]].data_ptr(),
+                g[ikeys[1]].data_ptr(), g[ikeys[2]].data_ptr(), g[ikeys[3]].data_ptr(), 0,
                 uo.grad.data_ptr(), uo.table.shape[0], user_ids.data_ptr(), self.dXu.data_ptr(), user_ids.numel(),
-                io.grad.data_ptr(), io.table.shape[0], iid.data_ptr(), dXi.data_ptr(), iid.numel(), d, st),
-                "embedding_scatter_add2")
+                io.grad.data_ptr(), io.table.shape[0], iid.data_ptr(), dXi.data_ptr(), iid.numel(), st),
+                "backward_reduce2_scatter2")
         n_part = o2 + self.np_rows
         if self.dist:
             # user rows are disjoint across ranks: their squared norms add; the MLP part is already global; the item

@@ -589,3 +589,58 @@ def test_pair_launches_are_bitwise_the_single_tower_calls(B, d, H):
         P = H * K1 + H + d * H + d
         assert torch.equal(t_["a"]["bws"][: ns * P], t_["b"]["bws"][: ns * P])      # the weight-gradient slabs
     assert int(err.item()) == 0
+
+
+@pytest.mark.parametrize("B", [300, 6000])
+def test_reduce_and_scatter_in_one_launch_is_bitwise_the_two_calls(B):
+    """rihip_backward_reduce2_scatter2 = rihip_tower_backward_reduce2 + rihip_embedding_scatter_add2 (B = 6000: 94 / 188
+    slabs, i.e. the first reduction level rides in the scatter launch and the second follows)."""
+    import ctypes as C
+    from recommendit_amd import _lib as L
+    lib, dev = L.lib(), L.device()
+    d, H, n_rows = 64, 128, 3000
+    g = torch.Generator(device=dev); g.manual_seed(B)
+    f32 = dict(dtype=torch.float32, device=dev)
+    st = L.stream_ptr()
+    tw = []
+    for item in (0, 1):
+        Bt, K1 = B * (2 if item else 1), d + (18 if item else 0)
+        t_ = dict(B=Bt, K1=K1, table=torch.randn((n_rows, d), generator=g, **f32),
+                  ids=torch.randint(0, n_rows, (Bt,), device=dev, generator=g),
+                  genres=(torch.rand((Bt, 18), device=dev, generator=g) < 0.2).float() if item else None,
+                  W1=torch.randn((H, K1), generator=g, **f32) * 0.1, W2=torch.randn((d, H), generator=g, **f32) * 0.1,
+                  gout=torch.randn((Bt, d), generator=g, **f32), out=torch.randn((Bt, d), generator=g, **f32),
+                  den=torch.rand((Bt,), generator=g, **f32) + 0.5, hid=torch.relu(torch.randn((Bt, H), generator=g, **f32)),
+                  dX=torch.empty((Bt, d), **f32),
+                  ws=torch.empty((lib.rihip_tower_backward_workspace_floats(Bt, d, H, item),), **f32))
+        n = C.c_int(0)
+        L.check(lib.rihip_tower_backward_partial(t_["table"].data_ptr(), n_rows, t_["ids"].data_ptr(), L.ptr(t_["genres"]), Bt,
+                                                 d, H, t_["W1"].data_ptr(), t_["W2"].data_ptr(), t_["gout"].data_ptr(),
+                                                 t_["out"].data_ptr(), t_["den"].data_ptr(), t_["hid"].data_ptr(), 1.0,
+                                                 t_["dX"].data_ptr(), t_["ws"].data_ptr(), st, None, C.byref(n)), "partial")
+        t_["ns"] = n.value
+        tw.append(t_)
+
+    def outs():
+        return [[torch.empty((H, t_["K1"]), **f32), torch.empty((H,), **f32), torch.empty((d, H), **f32),
+                 torch.empty((d,), **f32)] for t_ in tw], [torch.full((n_rows, d), 0.25, **f32) for _ in tw]
+
+    def red_args(gr):
+        a = [d, H]
+        for i, t_ in enumerate(tw):
+            a += [t_["ws"].data_ptr(), t_["B"], i, t_["ns"]] + [x.data_ptr() for x in gr[i]]
+        return a + [0]
+
+    def scat_args(tabs):
+        a = []
+        for i, t_ in enumerate(tw):
+            a += [tabs[i].data_ptr(), n_rows, t_["ids"].data_ptr(), t_["dX"].data_ptr(), t_["B"]]
+        return a
+
+    g1, t1 = outs()
+    L.check(lib.rihip_tower_backward_reduce2(*red_args(g1), st), "reduce2")
+    L.check(lib.rihip_embedding_scatter_add2(*scat_args(t1), d, st), "scatter2")
+    g2, t2 = outs()
+    L.check(lib.rihip_backward_reduce2_scatter2(*red_args(g2), *scat_args(t2), st), "fused")
+    for a_, b_ in zip(g1[0] + g1[1] + t1, g2[0] + g2[1] + t2):
+        assert torch.equal(a_, b_)
