@@ -90,7 +90,7 @@ def table(legs, want, title, out):
 table(["head"], ["inbatch_sweep_kernel", "inbatch_gt_kernel", "tower_"], "Headline step: in-batch passes and towers", f"{tag}_pmc_headline.md")
 table(["sampled_step"], ["tower_", "bpr_pair", "rows_", "adam_rows"], "Sampled-negative step (B = 65 536): towers and row-sparse optimiser",
       f"{tag}_pmc_towers.md")
-table(["retrieval"], ["scan_bf16", "rerank", "finalize", "compact"], "Brute-force top-500 retrieval (4 096 queries x 1 M rows)",
+table(["retrieval"], ["scan_bf16", "refine", "rerank", "finalize", "compact"], "Brute-force top-500 retrieval (4 096 queries x 1 M rows)",
       f"{tag}_pmc_retrieval.md")
 table(["serve"], ["ivf_", "gbdt_", "finalize", "rank_features", "tower_fwd"], "cfg5 serve chain (batches of 256 + single requests)",
       f"{tag}_pmc_serve.md")
