@@ -402,6 +402,35 @@ def leg_retrieval(model, cfg, n_users_local, args, world, rank, dev, cpu):
     return out, idx, X
 
 
+def leg_lambdamart(dev):
+    """§8f-4: LambdaMART training on the GPU at the ML-1M ranker shape (the reference trains LightGBM on the CPU,
+    ranker.py:52-155): 6 040 queries, ~2.4 M rows x 50 features, 63 leaves, a few trees."""
+    import pandas as pd
+    from recommendit_amd import LightGBMRanker
+    rng = np.random.RandomState(0)
+    nq, F, n_trees = 6040, 50, 10
+    sizes = np.clip(rng.lognormal(5.6, 0.9, nq).astype(int), 20, 9000)
+    n = int(sizes.sum())
+    Xr = rng.randn(n, F).astype(np.float32)
+    y = ((Xr @ rng.randn(F) + 2.0 * rng.randn(n)) > 5.0).astype(np.float32)
+    cols = [f"f{i}" for i in range(F)]
+    df = pd.DataFrame(Xr, columns=cols)
+    df["label"] = y
+    df["query_id"] = np.repeat(np.arange(nq), sizes)
+    rk = LightGBMRanker(num_leaves=63, n_estimators=n_trees, learning_rate=0.05)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = rk.train(df, cols, backend="hip")
+    dt = time.perf_counter() - t0
+    out = {"metric": "lambdamart_trees_per_sec", "value": n_trees / dt, "unit": "trees/s", "ms_per_tree": dt / n_trees * 1e3,
+           "rows": n, "features": F, "queries": nq, "num_leaves": 63, "trees": n_trees,
+           "train_ndcg10_first_last": [res["train"]["ndcg@10"][0], res["train"]["ndcg@10"][-1]],
+           "note": "rihip_lambdamart_train incl. binning + upload; trees bit-identical to oracle/lambdamart_np "
+                   "(tests/test_gpu_lambdamart.py); lightgbm itself is not installed (parity unpinned)"}
+    log(f"[bench] LambdaMART training: {out['ms_per_tree']:.1f} ms/tree on {n} rows x {F} features")
+    return out
+
+
 def leg_serve(model, X, n_users_local, dev, cpu):
     """cfg5: user tower -> IVF-IP (100 lists, nprobe 10, 500 candidates) -> feature assembly -> LambdaMART -> top-20"""
     import tempfile
@@ -537,6 +566,11 @@ def main():
                     r = guarded("serve", lambda: leg_serve(model, X, n_users_local, dev, cpu_ok))
                     if r is not None:
                         secondary["serve"] = r
+            model = idx = X = None
+            torch.cuda.empty_cache()
+            r = guarded("lambdamart_train", lambda: leg_lambdamart(dev))
+            if r is not None:
+                secondary["lambdamart_train"] = r
         else:
             sampled, model = leg_sampled(cfg, args, world, rank, dev, cpu_ok)
             secondary["sampled_bpr"] = sampled
