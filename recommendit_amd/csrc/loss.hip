@@ -439,19 +439,24 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void inbatch_gt_kernel(Sw
   // registers for one whole iteration and goes to LDS at the top of iteration t+1 (published by that iteration's
   // barrier, read in iteration t+2).  vmcnt retires in order, so the wait for a tile only covers requests that are
   // at least one full iteration (64 MFMAs per wave) old -- the HBM stream of G never stalls the L2-resident tile.
-  f32x4 gc[4], gn[4], gq[4];  // G of tile, tile+1, tile+2
+  // G of tile, tile+1, ..., tile+GA.  With d <= 64 a tile is only 32 MFMAs per wave (0.85 us): the HBM stream of G needs
+  // four tiles of lead there, two at d = 128.
+  constexpr int GA = (D >= 128) ? 2 : 4;
+  f32x4 gs[GA + 1][4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) gc[q] = gn[q] = gq[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j <= GA; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gs[j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (t0 < t1) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) gc[q] = gp[(size_t)t0 * 256 + q];
+    for (int j = 0; j < GA; ++j)
+      if (t0 + j < t1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gs[j][q] = gp[(size_t)(t0 + j) * 256 + q];
+      }
     load_tile(t0);
     store_tile(0);
-    if (t0 + 1 < t1) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) gn[q] = gp[(size_t)(t0 + 1) * 256 + q];
-      load_tile(t0 + 1);  // stays in registers until the top of the first iteration
-    }
+    if (t0 + 1 < t1) load_tile(t0 + 1);  // stays in registers until the top of the first iteration
     __syncthreads();
   }
   int it = 0;
@@ -459,10 +464,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void inbatch_gt_kernel(Sw
   for (int64_t tile = t0; tile < t1; ++tile, it = (it == 2 ? 0 : it + 1)) {
     const int cur = it, nxt = (it + 1) % 3;
     if (tile + 1 < t1) store_tile(nxt);  // buffer nxt was last read two iterations ago
-    if (tile + 2 < t1) {
-      load_tile(tile + 2);
+    if (tile + 2 < t1) load_tile(tile + 2);
+    if (tile + GA < t1) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) gq[q] = gp[(size_t)(tile + 2) * 256 + q];
+      for (int q = 0; q < 4; ++q) gs[GA][q] = gp[(size_t)(tile + GA) * 256 + q];
     }
     const float* Yc = Ysh[cur];
 #pragma unroll
@@ -471,14 +476,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void inbatch_gt_kernel(Sw
       for (int s = 0; s < 4; ++s) {
         const int krow = 16 * hh + 4 * q + s;
 #pragma unroll
-        for (int t = 0; t < CT; ++t) out[t] = mfma32(gc[q][s], Yc[krow * LDY + t * 32 + r31], out[t]);
+        for (int t = 0; t < CT; ++t) out[t] = mfma32(gs[0][q][s], Yc[krow * LDY + t * 32 + r31], out[t]);
       }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      gc[q] = gn[q];
-      gn[q] = gq[q];
-    }
+    for (int j = 0; j < GA; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gs[j][q] = gs[j + 1][q];
     __syncthreads();
   }
 
