@@ -52,6 +52,57 @@ __global__ __launch_bounds__(256) void rank_features_kernel(const double* __rest
   X[i] = v;
 }
 
+// one wave per candidate row (nf <= 64 output columns): the user row (24 doubles) and the item row (23 doubles) are
+// read once, coalesced, by lanes 0..46; every output column then picks its operand from those lanes.  Same float64
+// operations in the same order as canon_feature (the genre sum runs left to right), so the bits are equal; the
+// one-thread-per-element kernel above did 2-36 scattered loads per element and serialised on the genre-affinity column.
+// Broadcasts from FIXED lanes go through v_readlane (scalar registers), only the per-column operand pick is a
+// ds_bpermute: 25 double shuffles per row through the LDS crossbar made a first version as slow as the old kernel.
+__device__ __forceinline__ double readlane_d(double x, int lane) {
+  const long long b = __double_as_longlong(x);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__global__ __launch_bounds__(256) void rank_features_wave_kernel(const double* __restrict__ user_tab, int64_t n_urows,
+                                                                 const double* __restrict__ item_tab, int64_t n_irows,
+                                                                 const int64_t* __restrict__ user_ids,
+                                                                 const int64_t* __restrict__ cand, int64_t n_rows, int kc,
+                                                                 const int* __restrict__ col_map, int nf, float* X) {
+  const int lane = threadIdx.x & 63;
+  const int c = lane < nf ? col_map[lane] : -1;
+  // operand lane of a plain copy column (c < 11 or a genre column); other columns ignore it
+  int src = 0;
+  if (c >= 0) {
+    if (c < 6) src = c;
+    else if (c < 11) src = UW + (c - 6);
+    else if (c >= 14 && c < 14 + NG) src = 6 + (c - 14);
+    else if (c >= 14 + NG) src = UW + 5 + (c - 14 - NG);
+  }
+  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += (int64_t)gridDim.x * 4) {
+    int64_t uid = user_ids[row / kc], iid = cand[row];
+    const bool pad = iid < 0;                      // padded candidate (-1) -> all-zero row
+    if (uid < 0 || uid >= n_urows) uid = 0;        // row 0 of both tables = the reference's defaults
+    if (iid < 0 || iid >= n_irows) iid = 0;
+    // lanes 0..23: u[lane]; lanes 24..46: it[lane - 24]
+    double v = 0.0;
+    if (lane < UW) v = user_tab[uid * UW + lane];
+    else if (lane < UW + IW) v = item_tab[iid * IW + (lane - UW)];
+    // genre_affinity: products on lanes 0..17 (their operands straight from the two rows), summed left to right
+    double pg = 0.0;
+    if (lane < NG) pg = user_tab[uid * UW + 6 + lane] * item_tab[iid * IW + 5 + lane];
+    double aff = 0.0;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) aff += readlane_d(pg, g);
+    const double u0 = readlane_d(v, 0), u1 = readlane_d(v, 1), i0 = readlane_d(v, UW), i1 = readlane_d(v, UW + 1);
+    double f = __shfl(v, src, 64);
+    if (c == 11) f = u0 - i0;
+    else if (c == 12) f = u1 / (i1 + 1e-8);
+    else if (c == 13) f = aff;
+    if (lane < nf) X[row * nf + lane] = (pad || c < 0) ? 0.f : (float)f;
+  }
+}
+
 // final stage of the serving chain: DataFrame.nlargest(k, "score") (src/serving/recommender.py:346) for every request of
 // a batch -- the k best ranker scores, ties keep the retrieval order, padded candidates (id < 0) last -- in one launch
 // instead of the where / sort / gather sequence of tensor ops (5 dependent launches per batch)
@@ -135,8 +186,15 @@ extern "C" int rihip_rank_features_build(const double* user_tab, int64_t n_user_
                 "rank_features_build: bad sizes");
   const int64_t n = nq * kc * nf;
   if (n == 0) return RIHIP_OK;
-  hipLaunchKernelGGL(rank_features_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     user_tab, n_user_rows, item_tab, n_item_rows, user_ids, cand_ids, nq, kc, col_map, nf, X);
+  if (nf <= 64) {
+    const int64_t n_rows = nq * kc, nb = (n_rows + 3) / 4;
+    hipLaunchKernelGGL(rank_features_wave_kernel, dim3((unsigned)(nb < 16384 ? nb : 16384)), dim3(256), 0,
+                       (hipStream_t)stream, user_tab, n_user_rows, item_tab, n_item_rows, user_ids, cand_ids, n_rows, kc,
+                       col_map, nf, X);
+  } else {
+    hipLaunchKernelGGL(rank_features_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       user_tab, n_user_rows, item_tab, n_item_rows, user_ids, cand_ids, nq, kc, col_map, nf, X);
+  }
   RIHIP_CHECK_LAUNCH();
   return RIHIP_OK;
 }
