@@ -416,8 +416,7 @@ class HipBPRTrainer:
             self._loss_fold = None if self.dist else (self.lpart.data_ptr(), lib.rihip_bpr_pair_nparts(B), 1.0 / B)
             if self.dist:  # mean over the global batch
                 self.dU.div_(self.world); self.dI.div_(self.world)
-                self.loss.div_(self.world)
-                all_reduce_sum_(self.loss, self.pg)
+                self.loss.div_(self.world)   # (summed over the ranks together with the squared norms below)
         else:
             self._inbatch(st)
 
@@ -508,8 +507,10 @@ class HipBPRTrainer:
         if self.dist:
             # user rows are disjoint across ranks: their squared norms add; the MLP part is already global; the item
             # part is global when the table is replicated and disjoint (-> added up) when it is row-sharded
-            sq = torch.stack([self.part[o1:o2].sum(), self.part[o2:n_part].sum()])
+            # the loss value (only reported, never consumed by the step) rides in the same small all-reduce
+            sq = torch.stack([self.part[o1:o2].sum(), self.part[o2:n_part].sum(), self.loss.double()])
             all_reduce_sum_(sq, self.pg)
+            self.loss.copy_(sq[2])
             self.part[o1:o2].zero_()
             self.part[o1] = sq[0]
             if self.item_rows:
@@ -616,8 +617,7 @@ class HipBPRTrainer:
         if self.dist:
             L.check(lib.rihip_sum_partials(self.lpart.data_ptr(), self.n_lparts, 1.0 / (G * (G - 1.0)),
                                            self.loss.data_ptr(), st), "sum_partials")
-            all_reduce_sum_(self.loss, self.pg)
-            self._loss_fold = None
+            self._loss_fold = None   # (summed over the ranks together with the squared norms in step())
         else:   # summed by the clip-coefficient launch
             self._loss_fold = (self.lpart.data_ptr(), self.n_lparts, 1.0 / (G * (G - 1.0)))
 
