@@ -226,14 +226,20 @@ __device__ __forceinline__ double leaf_gain(double G, double H, double l1, doubl
   const double t = thr_l1(G, l1);
   return t * t / (H + l2);
 }
-// best split of one leaf: wave w takes features w, w+4, ...; lane-sequential scan of the bins keeps the order fixed
-__global__ __launch_bounds__(256) void split_kernel(const long long* __restrict__ hist, int F, const int* __restrict__ nb,
-                                                    const unsigned char* __restrict__ used, double sg, double sh, double l1,
-                                                    double l2, int min_child, double min_hess, SplitInfo* out) {
-  __shared__ SplitInfo best_w[4];
+// best split of one leaf per workgroup (blockIdx.x = 0 / 1: the two children of a split in ONE launch): wave w takes
+// features w, w+16, ...; lane-sequential scan of the bins keeps the order fixed; ties go to the lower feature index
+__global__ __launch_bounds__(1024) void split_kernel(const long long* __restrict__ hist0, const long long* __restrict__ hist1,
+                                                     int F, const int* __restrict__ nb,
+                                                     const unsigned char* __restrict__ used, double sg, double sh, double l1,
+                                                     double l2, int min_child, double min_hess, SplitInfo* out0) {
+  constexpr int NWV = 16;
+  __shared__ SplitInfo best_w[NWV];
+  const long long* __restrict__ hist = blockIdx.x == 0 ? hist0 : hist1;
+  SplitInfo* out = out0 + blockIdx.x;
+  if (!hist) return;   // this child is not split further
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   SplitInfo best; best.gain = 0.0; best.feature = -1; best.bin = 0; best.glq = best.hlq = best.cl = 0; best.gq = best.hq = best.c = 0;
-  for (int f = w; f < F; f += 4) {
+  for (int f = w; f < F; f += NWV) {
     const int nbf = nb[f];
     if (!used[f] || nbf < 2) continue;
     const long long* h = hist + (size_t)f * NBIN * 3;
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(256) void split_kernel(const long long* __restrict_
   __syncthreads();
   if (tid == 0) {
     SplitInfo b = best_w[0];
-    for (int k = 1; k < 4; ++k) {
+    for (int k = 1; k < NWV; ++k) {
       const SplitInfo& o = best_w[k];
       if (o.feature >= 0 && (b.feature < 0 || o.gain > b.gain || (o.gain == b.gain && o.feature < b.feature))) b = o;
     }
@@ -598,10 +604,13 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
     return RIHIP_OK;
   };
   double sg = 0.0, sh = 0.0;
-  auto find_split = [&](const long long* h, SplitInfo* slot) {
-    hipLaunchKernelGGL(split_kernel, dim3(1), dim3(256), 0, st, h, F, d_nb, d_used, sg, sh, p->reg_alpha, p->reg_lambda,
-                       p->min_child_samples, p->min_sum_hessian, slot);
+  // best splits of up to two leaves (the children of a split) in one launch; a null histogram = leaf not tried
+  auto find_splits = [&](const long long* h0, const long long* h1, SplitInfo* slots) {
+    hipLaunchKernelGGL(split_kernel, dim3(h1 ? 2 : 1), dim3(1024), 0, st, h0, h1, F, d_nb, d_used, sg, sh, p->reg_alpha,
+                       p->reg_lambda, p->min_child_samples, p->min_sum_hessian, slots);
   };
+  SplitInfo* h_split = nullptr;   // pinned: the per-split read-back is on the critical path of the tree growth
+  if (hipHostMalloc((void**)&h_split, sizeof(SplitInfo) * 2) != hipSuccess) h_split = nullptr;
 
   std::vector<Tree> trees;
   std::vector<double> hist_rows;      // [round][2][nk]
@@ -659,15 +668,17 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
     hipLaunchKernelGGL(iota_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rowsA, n);
     int n_slots = 1;
     auto read_splits = [&](SplitInfo* dst, int cntS) -> int {
-      TCHK(hipMemcpyAsync(dst, d_split, sizeof(SplitInfo) * cntS, hipMemcpyDeviceToHost, st));
+      SplitInfo* via = h_split ? h_split : dst;
+      TCHK(hipMemcpyAsync(via, d_split, sizeof(SplitInfo) * cntS, hipMemcpyDeviceToHost, st));
       TCHK(hipStreamSynchronize(st));
+      if (via != dst) memcpy(dst, via, sizeof(SplitInfo) * cntS);
       return RIHIP_OK;
     };
     {
       Leaf root; root.b = 0; root.len = n; root.parent_node = -1; root.side = 0; root.slot = 0; root.has = false;
       rc = build_hist(rowsA, 0, n, hist);
       if (rc) break;
-      find_split(hist, d_split);
+      find_splits(hist, nullptr, d_split);
       rc = read_splits(&root.s, 1);
       if (rc) break;
       root.has = root.s.feature >= 0;
@@ -725,11 +736,19 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
       hipLaunchKernelGGL(hist_sub_kernel, dim3((unsigned)((HSZ + 255) / 256)), dim3(256), 0, st, hist + (size_t)par.slot * HSZ,
                          hist + (size_t)S.slot * HSZ, hist + (size_t)Bg.slot * HSZ, (int)HSZ);
       const bool tryL = L.len >= 2 * (int64_t)p->min_child_samples, tryR = R.len >= 2 * (int64_t)p->min_child_samples;
-      if (tryL) find_split(hist + (size_t)L.slot * HSZ, d_split);
-      if (tryR) find_split(hist + (size_t)R.slot * HSZ, d_split + 1);
       SplitInfo two[2];
-      rc = read_splits(two, 2);
-      if (rc) break;
+      memset(two, 0, sizeof(two));
+      two[0].feature = two[1].feature = -1;
+      if (tryL || tryR) {
+        // (grid of 2 whenever the right child is tried: a null left histogram makes workgroup 0 return at once)
+        const long long* hL = tryL ? hist + (size_t)L.slot * HSZ : nullptr;
+        const long long* hR = tryR ? hist + (size_t)R.slot * HSZ : nullptr;
+        if (tryR) hipLaunchKernelGGL(split_kernel, dim3(2), dim3(1024), 0, st, hL, hR, F, d_nb, d_used, sg, sh, p->reg_alpha,
+                                     p->reg_lambda, p->min_child_samples, p->min_sum_hessian, d_split);
+        else find_splits(hL, nullptr, d_split);
+        rc = read_splits(two, 2);
+        if (rc) break;
+      }
       L.s = two[0]; R.s = two[1];
       L.has = tryL && two[0].feature >= 0; R.has = tryR && two[1].feature >= 0;
       leaves[pick] = L;
@@ -768,6 +787,7 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
   hipStreamSynchronize(st);
   hipFree(ls); hipFree(hs); hipFree(lam); hipFree(hes); hipFree(gq); hipFree(hq); hipFree(rowsA); hipFree(rowsB); hipFree(flags);
   hipFree(scan); hipFree(hist); hipFree(d_sum); hipFree(d_mx); hipFree(d_used); hipFree(d_split); hipFree(scan_tmp);
+  if (h_split) hipHostFree(h_split);
   hipFree(d_feat); hipFree(d_bin); hipFree(d_lc); hipFree(d_rc); hipFree(d_leafv);
   T.release(); V.release(); hipFree(d_ub); hipFree(d_nb); hipFree(d_gain); hipFree(d_ks);
   if (rc) return rc;
