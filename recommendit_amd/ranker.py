@@ -143,8 +143,9 @@ class LightGBMRanker:
         dev = L.device()
 
         def pack(df):
-            X = torch.from_numpy(np.ascontiguousarray(df[feature_cols].values.astype(np.float32))).to(dev)
-            y = torch.from_numpy(np.ascontiguousarray(df[label_col].values.astype(np.float32))).to(dev)
+            # (copy=False: a float32 frame -- what feature_engineering.py writes -- is not copied a second time)
+            X = torch.from_numpy(np.ascontiguousarray(df[feature_cols].to_numpy(dtype=np.float32, copy=False))).to(dev)
+            y = torch.from_numpy(np.ascontiguousarray(df[label_col].to_numpy(dtype=np.float32, copy=False))).to(dev)
             g = np.ascontiguousarray(df.groupby(query_col, sort=False).size().values.astype(np.int32))
             return X, y, g
 
