@@ -314,7 +314,7 @@ def leg_ml1m(dev, cpu):
                     "roofline": {"bound": "mfma", "achieved": bb * n2 / d2 * flop_pair / 1e12,
                                  "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                  "frac": bb * n2 / d2 * flop_pair / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                 "note": "launch-bound regime: %d dependent kernel boundaries per step (~4.7 us each)" % (12 if mode == "sampled" else 20)}}
+                                 "note": "launch-bound regime: %d dependent launches per step (user + item tower share one launch each way, slab reduction rides in the scatter launch)" % (7 if mode == "sampled" else 13)}}
         log(f"[bench] {tag}: {bb * n2 / d2:,.0f} pairs/s, {d2 / n2 * 1e3:.3f} ms/step")
         del t2, m2, b2
     if cpu:
