@@ -247,8 +247,11 @@ __device__ __noinline__ void scan_slow_append(const float* col16, float th, int6
 // MODE 2 (top-T sample): every lane keeps the SAMPLE_T best scores of its stream (query, split, half of the rows) in
 // registers and writes only those: the r-th largest of the union is a LOWER bound of the sample's r-th largest (a
 // subset can only lose large scores), i.e. a safe threshold, and the sample pass writes 100x less.
+// (launch bounds: the filter (MODE 0) wants 3 workgroups per CU even at the price of 72 spilled registers -- 2 per CU
+// measured 2.27 instead of 2.04 ms per batch; the short sample passes spilled 130-250 registers at that bound and run
+// 1.6x faster with 2 per CU and none)
 template <int D, int MODE>
-__global__ __launch_bounds__(256, 3) void scan_bf16_kernel(ScanArgs a) {
+__global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void scan_bf16_kernel(ScanArgs a) {
   constexpr bool DENSE = MODE != 0;
   constexpr int LDB = D + 8, KB = D / 16;
   constexpr int NV = (TRB * (D / 8) + 255) / 256;  // 16-byte pieces staged per thread per stage
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(256, 3) void scan_bf16_kernel(ScanArgs a) {
     }
   };
   auto compute = [&](int buf, int64_t i) {
-#pragma unroll
+#pragma unroll 1
     for (int sub = 0; sub < TRB / 32; ++sub) {
       const __bf16* Xt = &Xs[buf][sub * 32 * LDB];
       f32x16 a0 = zero16(), a1 = zero16();
