@@ -1533,8 +1533,8 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
   const unsigned qgrid_b = (unsigned)((nq + QBB - 1) / QBB);
   int main_nsplit = 0;
   int seg_cap = 64;   // per (query, corpus split) segment: 4x the expected survivors, a power of two, set below
-  auto bf16_nsplit = [&](int64_t tiles) -> int {
-    int64_t ns = (3 * RIHIP_NCU + qgrid_b - 1) / qgrid_b;  // 3 resident workgroups per CU (launch bounds)
+  auto bf16_nsplit = [&](int64_t tiles, int wgs_per_cu = 3) -> int {
+    int64_t ns = (wgs_per_cu * RIHIP_NCU + qgrid_b - 1) / qgrid_b;  // resident workgroups per CU (launch bounds: filter 3, sample 2)
     if (ns > tiles) ns = tiles;
     if (ns < 1) ns = 1;
     if (ns > 65535) ns = 65535;
@@ -1551,13 +1551,13 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
   // holds more than SAMPLE_T of the sample's top `rank` -- with rank <= streams * SAMPLE_T / 4 (mean <= 2 per stream) a
   // stream overflows with probability ~2e-4, and an overflow only lowers the threshold (more survivors, same result).
   // Larger ranks keep the dense sample.
-  const bool sample_top = two_prec && (int64_t)rank * 4 <= (int64_t)2 * bf16_nsplit(sample_tiles) * SAMPLE_T;
-  const int64_t cap_s = sample_top ? (int64_t)2 * bf16_nsplit(sample_tiles) * SAMPLE_T : S;  // streams = 2 * nsplit
+  const bool sample_top = two_prec && (int64_t)rank * 4 <= (int64_t)2 * bf16_nsplit(sample_tiles, 2) * SAMPLE_T;
+  const int64_t cap_s = sample_top ? (int64_t)2 * bf16_nsplit(sample_tiles, 2) * SAMPLE_T : S;  // streams = 2 * nsplit
   auto run_scan = [&](const ScanArgs& args, int64_t tiles) -> int {
     ScanArgs x = args;
     if (two_prec) {
       x.Xb = h->Xb;
-      x.nsplit = bf16_nsplit(tiles);
+      x.nsplit = bf16_nsplit(tiles, x.dense ? 2 : 3);
       x.qgrid = (int)qgrid_b;
       if (!x.dense) {
         RIHIP_REQUIRE(x.nsplit <= 1024, RIHIP_ERR_SHAPE, "ip_index: %d corpus splits", x.nsplit);
