@@ -279,19 +279,23 @@ struct WalkArgs {
   const float* X; int64_t n; int F; int ldx;
   double* part;
 };
-__global__ __launch_bounds__(256, 2) void gbdt_walk_kernel(WalkArgs a) {
+// 8 waves per workgroup share one staged forest chunk and one candidate tile (the kernel needs 32 registers: the 63 KB of
+// LDS bound it to 2 workgroups per CU, i.e. 8 waves per CU with 4-wave workgroups -- too few for a walk that waits on
+// LDS 60 % of the time)
+constexpr int WALK_NW = 8;
+__global__ __launch_bounds__(64 * WALK_NW, 2) void gbdt_walk_kernel(WalkArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smemw[];
   unsigned char* rS = smemw;                                             // [R_CAP] records
   double* lS = reinterpret_cast<double*>(rS + sizeof(uint2) * R_CAP);    // [L8_CAP]
-  double* red = lS + L8_CAP;                                             // [4][64]
-  unsigned char* xS = reinterpret_cast<unsigned char*>(red + 4 * 64);    // [F][64] floats, transposed
+  double* red = lS + L8_CAP;                                             // [WALK_NW][64]
+  unsigned char* xS = reinterpret_cast<unsigned char*>(red + WALK_NW * 64);    // [F][64] floats, transposed
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int chunk = blockIdx.y;
   const int t0 = a.chunk[chunk], t1 = a.chunk[chunk + 1];
   const int r0 = a.rec_chunk_off[chunk], r1 = a.rec_chunk_off[chunk + 1];
   const int l0 = a.tree_leaf_off[t0], l1 = a.tree_leaf_off[t1];
-  for (int i = tid; i < (r1 - r0); i += 256) reinterpret_cast<uint2*>(rS)[i] = a.rec[r0 + i];
-  for (int i = tid; i < (l1 - l0); i += 256) lS[i] = a.leaves[l0 + i];
+  for (int i = tid; i < (r1 - r0); i += 64 * WALK_NW) reinterpret_cast<uint2*>(rS)[i] = a.rec[r0 + i];
+  for (int i = tid; i < (l1 - l0); i += 64 * WALK_NW) lS[i] = a.leaves[l0 + i];
   const unsigned char* xL = xS + lane * 4;
   const int64_t n_tiles = (a.n + 63) / 64;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -301,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void gbdt_walk_kernel(WalkArgs a) {
        // bank conflicts (lane-consecutive); the strided global reads of a candidate's row are absorbed by L1
       const int64_t gr = tile * 64 + lane;
       const float* xr = a.X + (gr < a.n ? gr : 0) * a.ldx;
-      for (int f = w; f < a.F; f += 4) {
+      for (int f = w; f < a.F; f += WALK_NW) {
         float x = (gr < a.n) ? xr[f] : 0.f;
         if (x != x) x = 0.f;         // missing type None: a NaN feature decides like 0.0 at every node
         reinterpret_cast<float*>(xS)[f * 64 + lane] = x;
@@ -310,12 +314,12 @@ __global__ __launch_bounds__(256, 2) void gbdt_walk_kernel(WalkArgs a) {
     __syncthreads();
     double acc = 0.0;
     constexpr int IL = 4;            // trees walked at once by every lane (independent LDS chains)
-    for (int tb = t0 + w; tb < t1; tb += 4 * IL) {
+    for (int tb = t0 + w; tb < t1; tb += WALK_NW * IL) {
       unsigned cur[IL];
       int dmax = 0;
 #pragma unroll
       for (int j = 0; j < IL; ++j) {
-        const int t = tb + 4 * j;
+        const int t = tb + WALK_NW * j;
         const bool on = t < t1;
         cur[j] = (unsigned)a.rec_root[on ? t : tb];
         const int dj = on ? a.tree_depth[t] : 0;
@@ -335,14 +339,18 @@ __global__ __launch_bounds__(256, 2) void gbdt_walk_kernel(WalkArgs a) {
       }
 #pragma unroll
       for (int j = 0; j < IL; ++j) {   // leaves are added in tree order: bitwise reproducible
-        const int t = tb + 4 * j;
+        const int t = tb + WALK_NW * j;
         if (t < t1) acc += lS[a.tree_leaf_off[t] - l0 + (*reinterpret_cast<const unsigned*>(rS + cur[j] + 4) >> 18)];
       }
     }
     red[w * 64 + lane] = acc;
     __syncthreads();
-    if (w == 0 && row < a.n)
-      a.part[(size_t)chunk * a.n + row] = ((red[lane] + red[64 + lane]) + red[128 + lane]) + red[192 + lane];
+    if (w == 0 && row < a.n) {
+      double s = red[lane];
+#pragma unroll
+      for (int k = 1; k < WALK_NW; ++k) s += red[k * 64 + lane];   // fixed order
+      a.part[(size_t)chunk * a.n + row] = s;
+    }
   }
 }
 
@@ -672,17 +680,17 @@ extern "C" int rihip_gbdt_predict(void* handle, const float* X, int64_t n, int l
     c.rec = F->d_rec; c.leaves = F->d_leaves; c.tree_leaf_off = F->d_tree_leaf_off; c.chunk = F->d_chunk8;
     c.rec_chunk_off = F->d_rec_chunk_off; c.rec_root = F->d_rec_root; c.tree_depth = F->d_depth8;
     c.X = X; c.n = n; c.F = F->n_features; c.ldx = ldx; c.part = F->d_part;
-    const size_t lds = sizeof(uint2) * R_CAP + sizeof(double) * (L8_CAP + 4 * 64) + sizeof(float) * 64 * (size_t)F->n_features;
+    const size_t lds = sizeof(uint2) * R_CAP + sizeof(double) * (L8_CAP + WALK_NW * 64) + sizeof(float) * 64 * (size_t)F->n_features;
     static bool granted_w = false;
     if (!granted_w) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gbdt_walk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(sizeof(uint2) * R_CAP + sizeof(double) * (L8_CAP + 4 * 64) + sizeof(float) * 64 * 255));
+                                (int)(sizeof(uint2) * R_CAP + sizeof(double) * (L8_CAP + WALK_NW * 64) + sizeof(float) * 64 * 255));
       granted_w = true;
     }
     const int64_t n_tiles8 = (n + 63) / 64;
     int64_t per_chunk = (2 * RIHIP_NCU + n_chunks - 1) / n_chunks;     // 2 resident workgroups per CU over all chunks
     if (per_chunk > n_tiles8) per_chunk = n_tiles8;
-    hipLaunchKernelGGL(gbdt_walk_kernel, dim3((unsigned)per_chunk, n_chunks), dim3(256), lds, st, c);
+    hipLaunchKernelGGL(gbdt_walk_kernel, dim3((unsigned)per_chunk, n_chunks), dim3(64 * WALK_NW), lds, st, c);
     RIHIP_CHECK_LAUNCH();
     const double scale_w = F->average_output ? 1.0 / (double)F->n_trees : 1.0;
     hipLaunchKernelGGL(gbdt_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, F->d_part, n_chunks, n, scale_w, out);
