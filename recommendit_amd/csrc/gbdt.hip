@@ -282,7 +282,7 @@ struct WalkArgs {
 // 8 waves per workgroup share one staged forest chunk and one candidate tile (the kernel needs 32 registers: the 63 KB of
 // LDS bound it to 2 workgroups per CU, i.e. 8 waves per CU with 4-wave workgroups -- too few for a walk that waits on
 // LDS 60 % of the time)
-constexpr int WALK_NW = 8;
+constexpr int WALK_NW = 16;
 __global__ __launch_bounds__(64 * WALK_NW, 2) void gbdt_walk_kernel(WalkArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smemw[];
   unsigned char* rS = smemw;                                             // [R_CAP] records
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(64 * WALK_NW, 2) void gbdt_walk_kernel(WalkArgs a) 
     }
     __syncthreads();
     double acc = 0.0;
-    constexpr int IL = 4;            // trees walked at once by every lane (independent LDS chains)
+    constexpr int IL = 2;            // trees walked at once by every lane (independent LDS chains)
     for (int tb = t0 + w; tb < t1; tb += WALK_NW * IL) {
       unsigned cur[IL];
       int dmax = 0;
