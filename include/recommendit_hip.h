@@ -34,6 +34,11 @@ int rihip_abi_version(void);
 const char* rihip_target_arch(void);
 /* last error message of the calling thread ("" if none) */
 const char* rihip_last_error(void);
+/* Generation of the library state a captured hipGraph can have baked in: handle-owned scratch buffers of the index and
+ * the forest (grown on demand: the old allocation is freed), nprobe, the id map, the index / forest content.  Bumped on
+ * every such change, library-wide.  A caller that replays a captured chain (GpuRecommendationPipeline, the batched form
+ * of recommender.py:269-387) records the value after capture and re-captures when it differs. */
+uint64_t rihip_scratch_generation(void);
 /* name of device 0's ISA as reported by the runtime (host buffer); needs a GPU */
 int rihip_device_arch(char* buf, int buf_len);
 
@@ -240,6 +245,16 @@ int rihip_adam_rows(float* table, float* m, float* v, const int64_t* uniq, const
 int64_t rihip_route_workspace_bytes(int64_t B);
 int rihip_route_rows(const int64_t* ids, int64_t B, int world, int64_t* sorted_local, int64_t* perm, int64_t* pos,
                      int64_t* counts, int* err_flag, void* workspace, int64_t workspace_bytes, void* stream);
+/* Fixed-capacity form (no split size ever crosses to the host: equal-split all-to-alls of `cap` slots per peer):
+ * slot_ids int64[world*cap] = owner-local rows in slot (owner*cap + position), 0 (the padding row: gradient dropped by
+ * the row-sparse optimiser) in unused slots; slot_of_pair int64[B] = slot of each pair = its row in the
+ * [world*cap, d] received-rows staging table; counts int64[world] (device).  cap = B can never overflow; a smaller cap
+ * that does sets bit 2 of *err_flag.  scatter_rows: out[slot[i]] = src[i] (row gradients into their send slots). */
+int rihip_route_rows_fixed(const int64_t* ids, int64_t B, int world, int64_t cap, int64_t* slot_ids,
+                           int64_t* slot_of_pair, int64_t* counts, int* err_flag, void* workspace,
+                           int64_t workspace_bytes, void* stream);
+int rihip_scatter_rows(const float* src, const int64_t* slot, int64_t n, int64_t n_slots, int d, float* out,
+                       int* err_flag, void* stream);
 int rihip_gather_rows(const float* table, int64_t n_rows, const int64_t* ids, int64_t n, int d, float* out,
                       int* err_flag, void* stream);
 

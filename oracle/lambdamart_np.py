@@ -216,7 +216,7 @@ def train(X: np.ndarray, y: np.ndarray, groups: Sequence[int], params: Optional[
     scores = np.zeros(n)
     vscores = np.zeros(len(Xv)) if Xv is not None else None
     trees, history = [], []
-    best_val, best_it, since = None, 0, None
+    best_val, best_it, best_itr = None, 0, None
     n_used = max(1, int(F * p["feature_fraction"] + 0.5)) if p["feature_fraction"] < 1.0 else F
     for it in range(p["n_estimators"]):
         lam, hes = lambdarank_grads(scores, y, groups, p)
@@ -289,22 +289,29 @@ def train(X: np.ndarray, y: np.ndarray, groups: Sequence[int], params: Optional[
             vscores += predict_tree_binned(tree, Xvb)
             rec["valid"] = ndcg_at(vscores, yv, groups_v, p["eval_at"], gain_tab)
             cur = rec["valid"]
+            # lightgbm.early_stopping (callback.py, first_metric_only=False): per-metric best score / best iteration;
+            # the metrics are visited in order, the first whose patience ran out stops the run and names
+            # best_iteration; a run that reaches n_estimators reports metric 0's best iteration
+            stop = False
             if best_val is None:
-                best_val, since, best_it = list(cur), [0] * len(cur), it + 1
+                best_val, best_itr, best_it = list(cur), [it + 1] * len(cur), it + 1
             else:
                 for t, v in enumerate(cur):
                     if v > best_val[t]:
-                        best_val[t], since[t] = v, 0
-                        if t == 0:
-                            best_it = it + 1
-                    else:
-                        since[t] += 1
+                        best_val[t], best_itr[t] = v, it + 1
+                    elif it + 1 - best_itr[t] >= p["early_stopping_rounds"]:
+                        stop, best_it = True, best_itr[t]
+                        break
+                if not stop:
+                    best_it = best_itr[0]
             history.append(rec)
-            if max(since) >= p["early_stopping_rounds"]:
+            if stop:
                 break
         else:
             history.append(rec)
             best_it = it + 1
+    if Xvb is not None and 0 < best_it < len(trees):
+        trees = trees[:best_it]     # Booster.predict / save_model default to best_iteration after early stopping
     names = feature_names or [f"Column_{i}" for i in range(F)]
     return dict(feature_names=names, max_feature_idx=F - 1, num_class=1, num_tree_per_iteration=1, average_output=False,
                 objective="lambdarank", trees=trees, best_iteration=best_it, history=history, bounds=bounds)

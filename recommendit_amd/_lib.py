@@ -26,6 +26,7 @@ SIGNATURES = {
     "rihip_abi_version": (C.c_int, []),
     "rihip_target_arch": (C.c_char_p, []),
     "rihip_last_error": (C.c_char_p, []),
+    "rihip_scratch_generation": (C.c_uint64, []),
     "rihip_device_arch": (C.c_int, [C.c_char_p, C.c_int]),
     "rihip_tower_supported": (C.c_int, [C.c_int, C.c_int]),
     "rihip_tower_forward_workspace_floats": (c_i64, [C.c_int, C.c_int, C.c_int]),
@@ -82,6 +83,8 @@ SIGNATURES = {
     "rihip_route_workspace_bytes": (c_i64, [c_i64]),
     "rihip_route_rows": (C.c_int, [vp, c_i64, C.c_int, vp, vp, vp, vp, vp, vp, c_i64, vp]),
     "rihip_gather_rows": (C.c_int, [vp, c_i64, vp, c_i64, C.c_int, vp, vp, vp]),
+    "rihip_route_rows_fixed": (C.c_int, [vp, c_i64, C.c_int, c_i64, vp, vp, vp, vp, vp, c_i64, vp]),
+    "rihip_scatter_rows": (C.c_int, [vp, vp, c_i64, c_i64, C.c_int, vp, vp, vp]),
     "rihip_ip_index_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
     "rihip_ip_index_destroy": (C.c_int, [vp]),
     "rihip_ip_index_set_vectors": (C.c_int, [vp, vp, c_i64, C.c_int, vp]),

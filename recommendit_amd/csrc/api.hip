@@ -2,6 +2,7 @@
 #include "common.h"
 #include "recommendit_hip.h"
 
+#include <atomic>
 #include <stdarg.h>
 #include <string.h>
 
@@ -13,6 +14,10 @@ void rihip_set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+static std::atomic<uint64_t> g_generation{1};
+void rihip_bump_generation(void) { g_generation.fetch_add(1, std::memory_order_relaxed); }
+extern "C" uint64_t rihip_scratch_generation(void) { return g_generation.load(std::memory_order_relaxed); }
 
 extern "C" int rihip_abi_version(void) { return RIHIP_ABI_VERSION; }
 extern "C" const char* rihip_target_arch(void) { return "gfx950"; }

@@ -12,6 +12,9 @@
 #define RIHIP_ERR_STATE 5
 
 void rihip_set_error(const char* fmt, ...);
+// Library-wide generation of everything a captured hipGraph may have baked in (handle-owned scratch pointers, nprobe,
+// id maps, index / forest content): bumped whenever such state is reallocated, freed or changed.
+void rihip_bump_generation(void);
 
 #define RIHIP_CHECK_HIP(expr)                                                          \
   do {                                                                                 \

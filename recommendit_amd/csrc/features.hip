@@ -115,12 +115,16 @@ __global__ __launch_bounds__(256) void rank_topk_kernel(const double* __restrict
   const int64_t q = blockIdx.x;
   const int tid = threadIdx.x;
   for (int i = tid; i < P; i += 256) {
-    unsigned long long kk = 0ull;   // below every real score, -inf included
+    unsigned long long kk = 0ull;   // slots past kc: below everything
     if (i < kc) {
-      const double v = cand[q * kc + i] >= 0 ? scores[q * kc + i] : -INFINITY;
+      const bool real = cand[q * kc + i] >= 0;
+      const double v = real ? scores[q * kc + i] : -INFINITY;
       unsigned long long u = (unsigned long long)__double_as_longlong(v);
       kk = (u >> 63) ? ~u : (u | 0x8000000000000000ull);
-      if (kk == 0ull) kk = 1ull;
+      // padded candidates last (key 1), NaN scores just before them (key 2: DataFrame.nlargest never ranks a NaN above
+      // a number; a positive NaN would otherwise order above +inf), every number above both (key(-inf) = 2^52 - 1)
+      if (!real) kk = 1ull;
+      else if (v != v) kk = 2ull;
     }
     key[i] = kk; idx[i] = (unsigned short)i;
   }
@@ -153,15 +157,15 @@ extern "C" int rihip_rank_topk(const double* scores, const int64_t* cand, const 
                                int k, int64_t* out_ids, double* out_scores, float* out_retrieval_scores, void* stream) {
   RIHIP_REQUIRE(scores && cand && retrieval_scores && out_ids && out_scores && out_retrieval_scores, RIHIP_ERR_ARG,
                 "rank_topk: null pointer");
-  RIHIP_REQUIRE(nq >= 0 && kc >= 1 && kc <= 8192 && k >= 1, RIHIP_ERR_ARG, "rank_topk: kc=%d (1..8192), k=%d", kc, k);
+  RIHIP_REQUIRE(nq >= 0 && kc >= 1 && kc <= 16384 && k >= 1, RIHIP_ERR_ARG, "rank_topk: kc=%d (1..16384), k=%d", kc, k);
   if (nq == 0) return RIHIP_OK;
   int P = 64;
   while (P < kc || P < k) P <<= 1;
-  RIHIP_REQUIRE(P <= 8192, RIHIP_ERR_ARG, "rank_topk: k=%d too large", k);
+  RIHIP_REQUIRE(P <= 16384, RIHIP_ERR_ARG, "rank_topk: k=%d too large", k);   // = the index's K_MAX: 160 KiB of LDS
   const size_t lds = (size_t)P * 10;
   static bool granted = false;
   if (!granted) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rank_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 10);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rank_topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 10);
     granted = true;
   }
   hipLaunchKernelGGL(rank_topk_kernel, dim3((unsigned)nq), dim3(256), lds, (hipStream_t)stream, scores, cand, retrieval_scores,

@@ -585,6 +585,7 @@ int upload(const std::vector<T>& v, T** d) {
 
 void destroy_forest(Forest* F) {
   if (!F) return;
+  rihip_bump_generation();
   hipFree(F->d_nodes); hipFree(F->d_leaves); hipFree(F->d_tree_node_off); hipFree(F->d_tree_leaf_off); hipFree(F->d_tree_root);
   hipFree(F->d_chunk); hipFree(F->d_cat_b); hipFree(F->d_cat_w); hipFree(F->d_tree_cat_b_off); hipFree(F->d_tree_cat_w_off);
   hipFree(F->d_part); hipFree(F->d_nodes8); hipFree(F->d_chunk8); hipFree(F->d_depth8); hipFree(F->d_rec); hipFree(F->d_rec_chunk_off); hipFree(F->d_rec_root);
@@ -670,7 +671,7 @@ extern "C" int rihip_gbdt_predict(void* handle, const float* X, int64_t n, int l
   const bool compact = F->compact && F->d_nodes8 != nullptr;
   const int n_chunks = compact ? (int)F->chunk8.size() - 1 : (int)F->chunk_tree_start.size() - 1;
   if (F->part_elems < (int64_t)n_chunks * n) {
-    if (F->d_part) hipFree(F->d_part);
+    if (F->d_part) { hipFree(F->d_part); rihip_bump_generation(); }   // graphs that captured the old buffer are stale
     F->d_part = nullptr; F->part_elems = 0;
     RIHIP_CHECK_HIP(hipMalloc((void**)&F->d_part, sizeof(double) * (size_t)n_chunks * n));
     F->part_elems = (int64_t)n_chunks * n;

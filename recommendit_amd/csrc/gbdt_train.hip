@@ -614,7 +614,7 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
 
   std::vector<Tree> trees;
   std::vector<double> hist_rows;      // [round][2][nk]
-  std::vector<double> best_val; std::vector<int> since;
+  std::vector<double> best_val; std::vector<int> best_itr;
   int best_it = 0, rounds = 0;
   const int n_used = p->feature_fraction < 1.0 ? std::max(1, (int)(F * p->feature_fraction + 0.5)) : F;
   GradArgs ga;
@@ -633,12 +633,15 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
       for (int t = 0; t < nk; ++t) hist_rows.push_back(has_valid ? va[t] : NAN);
       rounds = it;
       if (has_valid) {
-        if (best_val.empty()) { best_val = va; since.assign(nk, 0); best_it = it; }
-        else for (int t = 0; t < nk; ++t) {
-          if (va[t] > best_val[t]) { best_val[t] = va[t]; since[t] = 0; if (t == 0) best_it = it; }
-          else since[t]++;
+        // lightgbm.early_stopping semantics (callback.py, first_metric_only=False): every validation metric keeps its
+        // own best score / best iteration; the metrics are visited in order and the FIRST one whose patience ran out
+        // stops the run and names best_iteration; a run that reaches n_estimators reports metric 0's best iteration
+        if (best_val.empty()) { best_val = va; best_itr.assign(nk, it); best_it = it; }
+        else for (int t = 0; t < nk && !stop; ++t) {
+          if (va[t] > best_val[t]) { best_val[t] = va[t]; best_itr[t] = it; }
+          else if (it - best_itr[t] >= p->early_stopping_rounds) { stop = true; best_it = best_itr[t]; }
         }
-        if (*std::max_element(since.begin(), since.end()) >= p->early_stopping_rounds) stop = true;
+        if (!stop) best_it = best_itr[0];
       } else best_it = it;
     }
     if (it == p->n_estimators || stop) break;
@@ -793,6 +796,9 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
   if (rc) return rc;
 
   // ---- LightGBM text model (Booster.save_model layout, src/models/ranker.py:203-209)
+  // with a validation set the model served and saved is the best iteration's (Booster.predict / save_model default to
+  // best_iteration after lgb.early_stopping, ranker.py:129-138, :174, :209): drop the trees grown past it
+  if (has_valid && best_it > 0 && (size_t)best_it < trees.size()) trees.resize((size_t)best_it);
   std::vector<std::string> blocks;
   for (size_t t = 0; t < trees.size(); ++t) blocks.push_back(tree_to_text(trees[t], (int)t, p->learning_rate));
   std::string names = feature_names ? feature_names : "";

@@ -17,7 +17,7 @@ struct DevBuf {
   int64_t n = 0;
   int reserve(int64_t want) {
     if (n >= want) return RIHIP_OK;
-    if (p) hipFree(p);
+    if (p) { hipFree(p); rihip_bump_generation(); }   // a graph that captured the old pointer is stale now
     p = nullptr; n = 0;
     if (hipMalloc((void**)&p, sizeof(T) * (size_t)want) != hipSuccess) {
       rihip_set_error("ip_index: device allocation of %lld bytes failed", (long long)(sizeof(T) * (size_t)want));
@@ -26,7 +26,7 @@ struct DevBuf {
     n = want;
     return RIHIP_OK;
   }
-  void release() { if (p) hipFree(p); p = nullptr; n = 0; }
+  void release() { if (p) { hipFree(p); rihip_bump_generation(); } p = nullptr; n = 0; }
 };
 
 struct IpIndex {
@@ -59,6 +59,7 @@ struct IpIndex {
 };
 
 inline void free_index_arrays(IpIndex* h) {
+  rihip_bump_generation();
   hipFree(h->X); hipFree(h->C); hipFree(h->tile_list); hipFree(h->list_poff); hipFree(h->list_len_dev); hipFree(h->row_ids); hipFree(h->Xb);
   h->X = nullptr; h->C = nullptr; h->tile_list = nullptr; h->list_poff = nullptr; h->list_len_dev = nullptr; h->row_ids = nullptr; h->Xb = nullptr;
   h->N = 0; h->Np = 0; h->ivf = false; h->nlist = 0; h->list_len.clear();

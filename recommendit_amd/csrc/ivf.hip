@@ -269,6 +269,7 @@ int build_lists(IpIndex* h, int nlist, float* C, Grouper& g, hipStream_t st) {
   hipFree(h->Xb);  // the IVF scan never reads the bf16 filter copy
   h->Xb = nullptr;
   h->X = Xn; h->Np = Np; h->nlist = nlist; h->ivf = true; h->C = C;
+  rihip_bump_generation();
   return derive_ivf_aux(h, st);
 }
 

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void rows_combine_kernel(const float* __restri
     for (int c = lane; c < d; c += 64) {
       float s = P[(size_t)s0 * d + c];
 #pragma unroll 8
-      for (int q = q0; q < s1; q += RB) s += P[(size_t)q * d + c];
+      for (int q = pad ? s1 : q0; q < s1; q += RB) s += P[(size_t)q * d + c];
       if (pad) s = 0.f;
       Gc[(size_t)u * d + c] = s;
       acc += (double)s * (double)s;
@@ -300,8 +300,9 @@ __global__ __launch_bounds__(256) void rows_combine_v4_kernel(const float* __res
     const bool pad = uniq[u] == 0;  // padding_idx row: gradient forced to zero (nn.Embedding semantics)
     const int q0 = (s0 / RB + 1) * RB;
     f32x4 s = reinterpret_cast<const f32x4*>(P + (size_t)s0 * d)[c4];
+    // (the padding row's segment can be tens of thousands of slots long in the fixed-capacity row exchange: not summed)
 #pragma unroll 4
-    for (int q = q0; q < s1; q += RB) {
+    for (int q = pad ? s1 : q0; q < s1; q += RB) {
       const f32x4 v = reinterpret_cast<const f32x4*>(P + (size_t)q * d)[c4];
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }

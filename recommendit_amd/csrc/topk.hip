@@ -1750,6 +1750,7 @@ extern "C" int rihip_ip_index_set_two_precision(void* handle, int enable) {
   IpIndex* h = (IpIndex*)handle;
   RIHIP_REQUIRE(h, RIHIP_ERR_ARG, "ip_index_set_two_precision: null handle");
   h->two_precision = enable ? 1 : 0;
+  rihip_bump_generation();
   return RIHIP_OK;
 }
 
@@ -1760,6 +1761,7 @@ extern "C" int rihip_ip_index_max_k(void) { return K_MAX; }
 extern "C" int rihip_ip_index_set_nprobe(void* handle, int nprobe) {
   IpIndex* h = (IpIndex*)handle;
   RIHIP_REQUIRE(h && nprobe >= 1, RIHIP_ERR_ARG, "ip_index_set_nprobe: bad arguments");
+  if (h->nprobe != nprobe) rihip_bump_generation();
   h->nprobe = nprobe;
   return RIHIP_OK;
 }
@@ -1784,6 +1786,7 @@ extern "C" int rihip_ip_index_search(void* handle, const float* Q, int64_t nq, i
 extern "C" int rihip_ip_index_set_id_map(void* handle, const int64_t* item_ids_dev) {
   IpIndex* h = (IpIndex*)handle;
   RIHIP_REQUIRE(h, RIHIP_ERR_ARG, "ip_index_set_id_map: null handle");
+  if (h->id_map != item_ids_dev) rihip_bump_generation();
   h->id_map = item_ids_dev;   // not owned: must stay valid (>= ntotal entries) while searches run; NULL switches it off
   return RIHIP_OK;
 }

@@ -5,8 +5,19 @@ On MI355X the backend is "nccl" (= RCCL over xGMI) and tensors stay on the devic
 through host memory so the very same call sequence runs."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def direct() -> bool:
+    """RIHIP_COLLECTIVES=direct (default) | ring.  The 8 GPUs of an MI355X node form a full xGMI mesh of point-to-point
+    links (7 x ~153 GB/s per GPU): every peer is ONE hop away.  "direct" runs the all-gather of tower outputs and the
+    reduce-scatter of partial item gradients as equal-split all-to-alls (7 concurrent one-hop transfers of 1/W of the
+    data, then a local fixed-order sum) instead of RCCL's ring schedules (W-1 dependent steps); "ring" keeps
+    ncclAllGather / ncclReduceScatter.  Device tensors over RCCL only; the gloo rehearsal always takes the plain calls."""
+    return os.environ.get("RIHIP_COLLECTIVES", "direct") != "ring"
 
 
 def _staged(t: torch.Tensor, group) -> bool:
@@ -18,12 +29,30 @@ class _Done:
         return None
 
 
+class _DirectReduce:
+    """handle of the one-hop reduce-scatter: wait() orders the current stream after the exchange, then sums the W
+    received slices into `out` (fixed order)"""
+
+    def __init__(self, work, recv: torch.Tensor, out: torch.Tensor, world: int):
+        self.work, self.recv, self.out, self.world = work, recv, out, world
+
+    def wait(self) -> None:
+        self.work.wait()
+        # one launch; the association order inside is fixed by the kernel, not by arrival order: reproducible
+        torch.sum(self.recv.view(self.world, *self.out.shape), dim=0, out=self.out)
+
+
 def all_gather_into(out: torch.Tensor, inp: torch.Tensor, group=None, async_op: bool = False):
     """out[rank*n:(rank+1)*n] = inp of that rank (row-major concatenation over ranks).
     async_op=True (RCCL only): returns a work handle; the collective runs on RCCL's stream, ordered after the kernels
     already queued on the current stream, and `handle.wait()` orders later kernels after it -- lets an all-gather
     that is only needed two kernels later overlap with the kernel in between."""
     if inp.is_cuda and not _staged(inp, group) and async_op:
+        W = dist.get_world_size(group)
+        if direct() and W > 1:
+            # one-hop form: the same block goes to every peer (input replicated W times: 10 us of HBM copies at 4 MiB)
+            rep = inp.contiguous().unsqueeze(0).expand(W, *inp.shape).contiguous().view(W * inp.shape[0], *inp.shape[1:])
+            return dist.all_to_all_single(out, rep, group=group, async_op=True)
         return dist.all_gather_into_tensor(out, inp.contiguous(), group=group, async_op=True)
     _all_gather_sync(out, inp, group)
     return _Done()
@@ -66,6 +95,17 @@ def reduce_scatter_sum(out: torch.Tensor, inp: torch.Tensor, group=None, async_o
     """out = (sum over ranks of inp)[rank*n:(rank+1)*n], n = out.shape[0] (rows).  Same async contract as
     all_gather_into."""
     if inp.is_cuda and not _staged(inp, group):
+        W = dist.get_world_size(group)
+        if direct() and W > 1:
+            # one-hop form: slice p of every rank's partial goes straight to rank p, which adds the W slices in a fixed
+            # order (bitwise reproducible, independent of any ring schedule)
+            recv = torch.empty_like(inp)
+            work = dist.all_to_all_single(recv, inp.contiguous(), group=group, async_op=True)
+            h = _DirectReduce(work, recv, out, W)
+            if async_op:
+                return h
+            h.wait()
+            return _Done()
         w = dist.reduce_scatter_tensor(out, inp.contiguous(), group=group, async_op=async_op)
         return w if async_op else _Done()
     c = inp.detach().cpu().contiguous()          # gloo has no reduce_scatter: all-reduce on the host, keep own slice
@@ -89,22 +129,6 @@ def all_to_all_rows(out: torch.Tensor, inp: torch.Tensor, out_splits, in_splits,
         return _Done()
     w = dist.all_to_all_single(out, inp.contiguous(), out_splits, in_splits, group=group, async_op=async_op)
     return w if async_op else _Done()
-
-
-def exchange_counts(send_counts: torch.Tensor, group=None):
-    """send_counts int64[W] (device or host): rows this rank will send to each peer.  Returns two Python lists
-    (send, recv) -- the ONE host synchronisation of a sharded-table step (the split sizes of the all-to-alls)."""
-    W = dist.get_world_size(group)
-    if _staged(send_counts, group) or not send_counts.is_cuda:
-        s = send_counts.detach().cpu().contiguous()
-        r = torch.empty_like(s)
-        dist.all_to_all_single(r, s, group=group)
-        return s.tolist(), r.tolist()
-    both = torch.empty((2 * W,), dtype=send_counts.dtype, device=send_counts.device)
-    both[:W].copy_(send_counts)
-    dist.all_to_all_single(both[W:], both[:W].clone(), group=group)
-    h = both.cpu()
-    return h[:W].tolist(), h[W:].tolist()
 
 
 # ---- row-sharded tables: global row g >= 1 lives on rank (g-1) % W at local row (g-1) // W + 1; local row 0 is padding

@@ -188,10 +188,23 @@ class GpuRecommendationPipeline:
         uid = torch.as_tensor(user_ids, dtype=torch.long, device=L.device())
         return self._chain(uid, k)
 
+    def _graph_state(self):
+        """everything a captured chain bakes in besides the torch-owned tensors of its own pool: the library's scratch
+        generation (handle-owned buffers that are freed when they grow, nprobe, id map, index / forest content) and the
+        identity of the feature tables and of the three stage objects"""
+        ut, it = self.store.device_tables()
+        return (int(L.lib().rihip_scratch_generation()), ut.data_ptr(), it.data_ptr(), id(self.index), id(self.ranker),
+                id(self.model), self.top_k_candidates, tuple(self.ranker.feature_names))
+
     def _replay(self, user_ids, k: int):
         nq = len(user_ids)
         key = (nq, k)
         ent = self._graphs.get(key)
+        if ent is not None and ent is not False and ent[3] != self._graph_state():
+            # an eager call (or a capture of a larger shape) grew a scratch buffer, nprobe changed, the feature tables
+            # were reloaded, ...: the pointers inside this graph are stale -- drop it and capture again
+            ent = None
+            del self._graphs[key]
         if ent is None:
             dev = L.device()
             su = torch.ones((nq,), dtype=torch.long, device=dev)
@@ -207,14 +220,14 @@ class GpuRecommendationPipeline:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     out = self._chain(su, k)
-                ent = (g, su, out)
+                ent = (g, su, out, self._graph_state())     # recorded AFTER capture: the warm-up may have grown scratch
             except Exception:                        # a path with a host sync cannot be captured: stay eager for this shape
                 torch.cuda.synchronize()
                 ent = False
             self._graphs[key] = ent
         if ent is False:
             return None
-        g, su, out = ent
+        g, su, out, _ = ent
         su.copy_(torch.as_tensor(user_ids, dtype=torch.long), non_blocking=True)
         g.replay()
         return out

@@ -20,7 +20,8 @@ Multi-GPU (one process per GPU, torch.distributed/RCCL; opt-in with ``distribute
   * ``item_shard="rows"`` -- cut by rows (global row g on rank (g-1) % W, BASELINE cfg4): per step the batch's item ids
     are routed to their owners (ids all-to-all), the owners gather the rows and send them back (rows all-to-all), the
     item tower runs on the received rows, and the row gradients return to the owners (grads all-to-all), who apply the
-    row-sparse Adam to the rows they own.  One host sync per step (the split sizes).
+    row-sparse Adam to the rows they own.  The three all-to-alls use EQUAL splits of `exchange_cap` slots per peer
+    (default = the worst case nI: can never overflow), so no split size crosses to the host: the step has no host sync.
 In-batch negatives are global through an all-gather of the item-tower outputs; MLP grads are all-reduced; the clip norm
 is an all-reduced scalar.  See DESIGN.md "Multi-GPU".
 """
@@ -34,7 +35,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib as L
-from .dist_utils import all_gather_into, all_reduce_sum_, all_to_all_rows, exchange_counts, reduce_scatter_sum
+from .dist_utils import all_gather_into, all_reduce_sum_, all_to_all_rows, reduce_scatter_sum
 from .two_tower import TwoTowerModel
 
 _MLP_KEYS = ["user_tower.mlp.0.weight", "user_tower.mlp.0.bias", "user_tower.mlp.3.weight", "user_tower.mlp.3.bias",
@@ -112,11 +113,14 @@ class HipBPRTrainer:
                  betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = 1.0, loss_mode: str = "sampled",
                  table_opt: str = "dense", seed: int = 0, process_group=None, user_row_offset: int = 0,
                  inbatch_precision: int = 0, use_graph: bool = False, inbatch_store_g=None,
-                 distributed: bool = False, item_shard: str = "replicate"):
+                 distributed: bool = False, item_shard: str = "replicate", exchange_cap: Optional[int] = None):
         """distributed=True (or a process_group): this trainer is one rank of a collective job -- EVERY rank of the
         group must construct it and call step() in lock-step.  Default False even when torch.distributed is
         initialised, so that a single-rank trainer inside a distributed program never issues collectives.
-        item_shard="rows": model.item_tower.embedding holds only this rank's rows of the item table (see module doc)."""
+        item_shard="rows": model.item_tower.embedding holds only this rank's rows of the item table (see module doc).
+        exchange_cap: send slots per peer of the row exchange (None = nI, the worst case).  A smaller capacity saves
+        wire volume (W*cap*d*4 bytes per all-to-all) but a step that routes more than `cap` rows to one owner sets
+        error bit 2 (check_errors() raises)."""
         assert loss_mode in ("sampled", "inbatch") and table_opt in ("dense", "sparse")
         assert item_shard in ("replicate", "rows")
         self.lib = L.lib()
@@ -174,7 +178,9 @@ class HipBPRTrainer:
         nI = self.B * (2 if loss_mode == "sampled" else 1)
         self.nI = nI
         # replicated item table: applies every rank's rows; row-sharded: up to every rank's requests can hit one owner
-        nI_all = nI * self.world
+        cap = self.exchange_cap = (int(exchange_cap) if exchange_cap else nI) if self.item_rows else 0
+        assert not self.item_rows or 1 <= cap <= nI
+        nI_all = self.world * cap if self.item_rows else nI * self.world
         if table_opt == "sparse":
             self.uopt = _RowsOpt(self.utab, self.B)
             self.iopt = _RowsOpt(self.itab, nI_all)
@@ -246,17 +252,18 @@ class HipBPRTrainer:
             self.iid_all = torch.empty((W * nI,), dtype=torch.int64, device=self.dev)
             self.dXi_all = torch.empty((W * nI, d), **f32)
         if self.item_rows:
-            # routing state of one step (ids all-to-all -> rows all-to-all -> grads all-to-all), worst-case capacities
+            # routing state of one step (ids all-to-all -> rows all-to-all -> grads all-to-all): `cap` slots per peer
             W = self.world
             i64 = dict(dtype=torch.int64, device=self.dev)
+            nS = self.n_slots = W * cap
             self.rt_ws = torch.empty((self.lib.rihip_route_workspace_bytes(nI),), dtype=torch.uint8, device=self.dev)
-            self.rt_local = torch.empty((nI,), **i64); self.rt_perm = torch.empty((nI,), **i64)
-            self.rt_pos = torch.empty((nI,), **i64); self.rt_counts = torch.empty((W,), **i64)
-            self.req_ids = torch.empty((W * nI,), **i64)            # owner side: local rows requested by all ranks
-            self.rows_out = torch.empty((W * nI, d), **f32)         # owner side: those rows / their gradients
-            self.rows_in = torch.empty((nI, d), **f32)              # requester side: staging table the item tower reads
-            self.dX_sorted = torch.empty((nI, d), **f32)
-            self._n_req = 0
+            self.rt_slot_ids = torch.empty((nS,), **i64)            # requester: owner-local row per send slot (0 = unused)
+            self.rt_slot = torch.empty((nI,), **i64)                # requester: slot of each pair (= its row in rows_in)
+            self.rt_counts = torch.empty((W,), **i64)               # requester: requests per owner (device only)
+            self.req_ids = torch.empty((nS,), **i64)                # owner: local rows requested by every rank's slots
+            self.rows_out = torch.empty((nS, d), **f32)             # owner: those rows, later their gradients
+            self.rows_in = torch.empty((nS, d), **f32)              # requester: staging table the item tower reads
+            self.dX_slots = torch.zeros((nS, d), **f32)             # requester: row gradients in their send slots
 
     # ------------------------------------------------------------------------------------------
     def _fwd(self, table, ids, genres, keys, out, hid, den, seed):
@@ -387,9 +394,17 @@ class HipBPRTrainer:
             # row-sharded item table: the rows travel (all-to-all) under the user tower, then the item tower reads the
             # received rows as a [nI,d] staging table indexed by each pair's send slot
             w_rows = self._fetch_item_rows(item_ids, st)
+            if sparse:
+                # the owner's id list of this step is known as soon as the ids all-to-all lands: its sort / unique-row
+                # search (~12 small dependent kernels) runs beside the towers, not after the gradient exchange
+                ev_ids = torch.cuda.Event()
+                ev_ids.record(cur)
+                sideB.wait_event(ev_ids)
+                with torch.cuda.stream(sideB):
+                    self.iopt.group(self.req_ids, sideB.cuda_stream)
             self._fwd(self.utab, user_ids, None, ukeys, self.U, self.hidU, self.denU, s0)
             w_rows.wait()
-            itab, iids = self.rows_in, self.rt_pos
+            itab, iids = self.rows_in, self.rt_slot
             self._fwd(itab, iids, item_genres, ikeys, self.I, self.hidI, self.denI, s0 + 1)
             if self.loss_mode == "inbatch":
                 self._I_work = all_gather_into(self.I_all, self.I, self.pg, async_op=True)
@@ -458,14 +473,15 @@ class HipBPRTrainer:
         iid, dXi = item_ids, self.dXi
         w_i = w_x = None
         if self.item_rows:
-            # row gradients return to the owners of the rows, in the order the ids went out
-            L.check(lib.rihip_gather_rows(self.dXi.data_ptr(), self.nI, self.rt_perm.data_ptr(), self.nI, d,
-                                          self.dX_sorted.data_ptr(), self.err.data_ptr(), st), "gather_rows")
-            n_req = self._n_req
-            w_x = all_to_all_rows(self.rows_out[:n_req], self.dX_sorted, self._recv_counts, self._send_counts, self.pg,
-                                  async_op=True)
+            # row gradients return to the owners of the rows in the slots the ids went out in (unused slots carry
+            # whatever they held: the owner sees id 0 there and drops them)
+            nS = self.n_slots
+            L.check(lib.rihip_scatter_rows(self.dXi.data_ptr(), self.rt_slot.data_ptr(), self.nI, nS, d,
+                                           self.dX_slots.data_ptr(), self.err.data_ptr(), st), "scatter_rows")
+            eq = [self.exchange_cap] * self.world
+            w_x = all_to_all_rows(self.rows_out, self.dX_slots, eq, eq, self.pg, async_op=True)
             all_reduce_sum_(self.flat_g, self.pg)
-            iid, dXi = self.req_ids[:n_req], self.rows_out[:n_req]
+            iid, dXi = self.req_ids, self.rows_out
         elif self.dist:
             # the item row gradients travel while the MLP all-reduce and the user-row grouping run
             w_i = all_gather_into(self.iid_all, item_ids, self.pg, async_op=True)
@@ -483,6 +499,9 @@ class HipBPRTrainer:
             if iid.numel() > 0:
                 if early_item_group:
                     cur.wait_stream(sideB)
+                elif self.item_rows:      # grouped beside the towers (above); the sums need the gradients that just landed
+                    cur.wait_stream(sideB)
+                    self.iopt.reduce(dXi, pp + 8 * o2, st)
                 else:
                     self.iopt.group_reduce(iid, dXi, pp + 8 * o2, st)
             else:   # this rank owns none of the rows of the step
@@ -541,20 +560,34 @@ class HipBPRTrainer:
         return self.loss
 
     def _fetch_item_rows(self, item_ids: torch.Tensor, st: int):
-        """Row-sharded item table, forward half of the exchange: route the step's global item ids to their owners,
-        all-to-all the owner-local row numbers, gather the requested rows here, all-to-all them back (async handle).
-        Leaves: rt_pos (send slot of each pair = its row in rows_in), rt_perm, req_ids[:n_req], the split lists."""
-        lib, d, nI = self.lib, self.d, self.nI
-        L.check(lib.rihip_route_rows(item_ids.data_ptr(), nI, self.world, self.rt_local.data_ptr(),
-                                     self.rt_perm.data_ptr(), self.rt_pos.data_ptr(), self.rt_counts.data_ptr(),
-                                     self.err.data_ptr(), self.rt_ws.data_ptr(), self.rt_ws.numel(), st), "route_rows")
-        self._send_counts, self._recv_counts = exchange_counts(self.rt_counts, self.pg)   # the step's one host sync
-        n_req = self._n_req = int(sum(self._recv_counts))
-        all_to_all_rows(self.req_ids[:n_req], self.rt_local, self._recv_counts, self._send_counts, self.pg)
-        L.check(lib.rihip_gather_rows(self.itab.data_ptr(), self.itab.shape[0], self.req_ids.data_ptr(), n_req, d,
+        """Row-sharded item table, forward half of the exchange: route the step's global item ids into `cap` send slots
+        per owner, all-to-all the owner-local row numbers (equal splits: nothing crosses to the host), gather the
+        requested rows here, all-to-all them back (async handle).  Leaves rt_slot (slot of each pair = its row in
+        rows_in) and req_ids (0 = the padding row in unused slots)."""
+        lib, d, nI, nS = self.lib, self.d, self.nI, self.n_slots
+        L.check(lib.rihip_route_rows_fixed(item_ids.data_ptr(), nI, self.world, self.exchange_cap,
+                                           self.rt_slot_ids.data_ptr(), self.rt_slot.data_ptr(), self.rt_counts.data_ptr(),
+                                           self.err.data_ptr(), self.rt_ws.data_ptr(), self.rt_ws.numel(), st),
+                "route_rows_fixed")
+        eq = [self.exchange_cap] * self.world
+        all_to_all_rows(self.req_ids, self.rt_slot_ids, eq, eq, self.pg)
+        L.check(lib.rihip_gather_rows(self.itab.data_ptr(), self.itab.shape[0], self.req_ids.data_ptr(), nS, d,
                                       self.rows_out.data_ptr(), self.err.data_ptr(), st), "gather_rows")
-        return all_to_all_rows(self.rows_in, self.rows_out[:n_req], self._send_counts, self._recv_counts, self.pg,
-                               async_op=True)
+        return all_to_all_rows(self.rows_in, self.rows_out, eq, eq, self.pg, async_op=True)
+
+    def check_errors(self) -> None:
+        """Read the device error word (ONE host sync: call it per epoch / at the end of a run, not per step) and raise:
+        bit 1 = an id outside its table (negative, or beyond the rows of the shard), bit 2 = more than exchange_cap rows
+        routed to one owner in a step."""
+        e = int(self.err.item())
+        if e:
+            self.err.zero_()
+            what = []
+            if e & 1:
+                what.append("an id outside its embedding table")
+            if e & 2:
+                what.append(f"more than exchange_cap={getattr(self, 'exchange_cap', 0)} rows routed to one owner")
+            raise RuntimeError("HipBPRTrainer: " + " and ".join(what or [f"device error word {e}"]))
 
     def _timed(self, fn, what, *args) -> None:
         ev = self.sweep_events

@@ -66,53 +66,67 @@ def test_two_rank_inbatch_decomposition(tmp_path):
     np.testing.assert_allclose(np.concatenate([p["dI"] for p in parts]), dI, atol=1e-9)
 
 
-def _route_np(ids, W):
-    """NumPy restatement of rihip_route_rows (csrc/shard.hip): stable sort of the requests by owner rank"""
-    owner = (ids - 1) % W
-    perm = np.argsort(owner, kind="stable")
-    pos = np.empty_like(perm); pos[perm] = np.arange(len(ids))
-    return (ids[perm] - 1) // W + 1, perm, pos, np.bincount(owner, minlength=W).astype(np.int64)
+def _route_fixed_np(ids, W, cap):
+    """NumPy restatement of rihip_route_rows_fixed (csrc/shard.hip): `cap` send slots per owner, stable order inside an
+    owner, the padding id 0 -> rank 0's padding row, unused slots = 0"""
+    owner = np.where(ids < 1, 0, (ids - 1) % W)
+    local = np.where(ids < 1, 0, (ids - 1) // W + 1)
+    slot_ids = np.zeros(W * cap, dtype=np.int64)
+    slot = np.empty(len(ids), dtype=np.int64)
+    fill = np.zeros(W, dtype=np.int64)
+    for i in range(len(ids)):
+        c = owner[i]
+        assert fill[c] < cap
+        slot[i] = c * cap + fill[c]
+        slot_ids[slot[i]] = local[i]
+        fill[c] += 1
+    return slot_ids, slot, fill
 
 
 def _shard_worker(rank, world, port, nI, n_items, d, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from recommendit_amd.dist_utils import all_to_all_rows, exchange_counts, n_local_rows, shard_rows
+    from recommendit_amd.dist_utils import all_to_all_rows, n_local_rows, shard_rows
     rng = np.random.RandomState(5)
     full = rng.randn(n_items + 1, d).astype(np.float32)
     mine = shard_rows(full, rank, world)
     assert mine.shape[0] == n_local_rows(n_items, rank, world) + 1
     ids = np.random.RandomState(10 + rank).zipf(1.3, nI).clip(1, n_items).astype(np.int64)   # skewed, repeated ids
-    local, perm, pos, counts = _route_np(ids, world)
-    send, recv = exchange_counts(torch.from_numpy(counts))
-    assert send == counts.tolist()
-    n_req = sum(recv)
-    req = torch.empty((n_req,), dtype=torch.int64)
-    all_to_all_rows(req, torch.from_numpy(local), recv, send)
-    rows_out = torch.from_numpy(mine[req.numpy()])                       # owner-side gather
-    rows_in = torch.empty((nI, d))
-    all_to_all_rows(rows_in, rows_out, send, recv, async_op=True).wait()
-    np.testing.assert_array_equal(rows_in.numpy()[pos], full[ids])        # every pair got ITS row
-    # gradients travel back in send order; the owner sums duplicates
+    ids[3] = 0                                                            # a padded pair: row 0, no gradient
+    cap = nI                                                              # worst case: can never overflow
+    slot_ids, slot, _ = _route_fixed_np(ids, world, cap)
+    eq = [cap] * world                                                    # equal splits: nothing crosses to the host
+    req = torch.empty((world * cap,), dtype=torch.int64)
+    all_to_all_rows(req, torch.from_numpy(slot_ids), eq, eq)
+    rows_out = torch.from_numpy(mine[req.numpy()])                       # owner-side gather (unused slots read row 0)
+    rows_in = torch.empty((world * cap, d))
+    all_to_all_rows(rows_in, rows_out, eq, eq, async_op=True).wait()
+    exp = full[ids].copy(); exp[3] = shard_rows(full, 0, world)[0]        # id 0 reads rank 0's padding row
+    np.testing.assert_array_equal(rows_in.numpy()[slot], exp)             # every pair got ITS row
+    # gradients travel back in the slots the ids went out in; the owner sums duplicates and drops local row 0
     dX = np.random.RandomState(20 + rank).randn(nI, d).astype(np.float32)
-    g_in = torch.empty((n_req, d))
-    all_to_all_rows(g_in, torch.from_numpy(dX[perm]), recv, send)
+    dX_slots = np.full((world * cap, d), 7.0, dtype=np.float32)          # stale content in unused slots must not matter
+    dX_slots[slot] = dX
+    g_in = torch.empty((world * cap, d))
+    all_to_all_rows(g_in, torch.from_numpy(dX_slots), eq, eq)
     acc = np.zeros_like(mine, dtype=np.float64)
     np.add.at(acc, req.numpy(), g_in.numpy().astype(np.float64))
+    acc[0] = 0                                                            # padding_idx row: gradient forced to zero
     np.savez(os.path.join(out_dir, f"s{rank}.npz"), acc=acc, ids=ids, dX=dX)
     dist.destroy_process_group()
 
 
 def test_two_rank_row_sharded_exchange(tmp_path):
-    """ids all-to-all -> rows all-to-all -> grads all-to-all (HipBPRTrainer item_shard="rows") against the
-    single-table scatter-add"""
+    """ids all-to-all -> rows all-to-all -> grads all-to-all, all with equal splits of `cap` slots per peer
+    (HipBPRTrainer item_shard="rows": no host sync) against the single-table scatter-add"""
     world, nI, n_items, d = 2, 50, 37, 8
     mp.spawn(_shard_worker, args=(world, _free_port(), nI, n_items, d, str(tmp_path)), nprocs=world, join=True)
     parts = [np.load(tmp_path / f"s{r}.npz") for r in range(world)]
     ref = np.zeros((n_items + 1, d), dtype=np.float64)
     for p in parts:
         np.add.at(ref, p["ids"], p["dX"].astype(np.float64))
+    ref[0] = 0
     for r, p in enumerate(parts):
         np.testing.assert_allclose(p["acc"][1:], ref[1 + r::world], atol=1e-12)
         assert (p["acc"][0] == 0).all()

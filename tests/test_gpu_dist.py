@@ -184,3 +184,64 @@ def test_route_rows_and_gather_kernels_vs_numpy():
         out = torch.empty(B, 64, device=dev)
         L.check(lib.rihip_gather_rows(tab.data_ptr(), 257, gi.data_ptr(), B, 64, out.data_ptr(), err.data_ptr(), st), "gather")
         assert torch.equal(out, tab[gi]) and err.item() == 0
+
+
+def test_route_rows_fixed_and_scatter_kernels_vs_numpy():
+    """the fixed-capacity routing of the host-sync-free exchange against tests/test_dist_cpu.py::_route_fixed_np: slots,
+    padding id 0 -> rank 0's row 0, unused slots 0, counts on the device, overflow -> error bit 2, scatter into slots"""
+    from recommendit_amd import _lib as L
+    from test_dist_cpu import _route_fixed_np      # (tests/ is on sys.path: rootdir conftest, no package)
+    lib, dev, st = L.lib(), L.device(), L.stream_ptr()
+    rng = np.random.RandomState(4)
+    for B, W, n, cap in ((40, 2, 90, 40), (8192, 8, 10_000_000, 8192), (1000, 5, 7, 1000), (256, 256, 5000, 256),
+                         (4096, 8, 100000, 1024)):
+        ids = rng.zipf(1.2, B).clip(1, n).astype(np.int64)
+        ids[rng.randint(0, B, 3)] = 0
+        if cap < B:     # a capacity with slack: uniform ids stay below it
+            ids = rng.randint(1, n + 1, B).astype(np.int64)
+        i64 = dict(dtype=torch.int64, device=dev)
+        idd = torch.from_numpy(ids).to(dev)
+        slot_ids, slot, cnt = torch.full((W * cap,), -5, **i64), torch.empty(B, **i64), torch.empty(W, **i64)
+        ws = torch.empty(lib.rihip_route_workspace_bytes(B), dtype=torch.uint8, device=dev)
+        err = torch.zeros(1, dtype=torch.int32, device=dev)
+        L.check(lib.rihip_route_rows_fixed(idd.data_ptr(), B, W, cap, slot_ids.data_ptr(), slot.data_ptr(), cnt.data_ptr(),
+                                           err.data_ptr(), ws.data_ptr(), ws.numel(), st), "route_rows_fixed")
+        e_ids, e_slot, e_cnt = _route_fixed_np(ids, W, cap)
+        np.testing.assert_array_equal(slot_ids.cpu().numpy(), e_ids)
+        np.testing.assert_array_equal(slot.cpu().numpy(), e_slot)
+        np.testing.assert_array_equal(cnt.cpu().numpy(), e_cnt)
+        assert err.item() == 0
+        src = torch.randn(B, 64, device=dev)
+        out = torch.full((W * cap, 64), 3.0, device=dev)
+        L.check(lib.rihip_scatter_rows(src.data_ptr(), slot.data_ptr(), B, W * cap, 64, out.data_ptr(), err.data_ptr(), st),
+                "scatter_rows")
+        exp = torch.full((W * cap, 64), 3.0, device=dev)
+        exp[slot] = src
+        assert torch.equal(out, exp) and err.item() == 0
+    # overflow: every id owned by rank 1, capacity 16
+    B, W, cap = 64, 4, 16
+    idd = torch.full((B,), 2, dtype=torch.int64, device=dev)
+    slot_ids, slot, cnt = torch.empty(W * cap, dtype=torch.int64, device=dev), torch.empty(B, dtype=torch.int64, device=dev), \
+        torch.empty(W, dtype=torch.int64, device=dev)
+    ws = torch.empty(lib.rihip_route_workspace_bytes(B), dtype=torch.uint8, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    L.check(lib.rihip_route_rows_fixed(idd.data_ptr(), B, W, cap, slot_ids.data_ptr(), slot.data_ptr(), cnt.data_ptr(),
+                                       err.data_ptr(), ws.data_ptr(), ws.numel(), st), "route_rows_fixed")
+    assert err.item() & 2 and cnt.cpu().tolist() == [0, 16, 0, 0]
+    assert int(slot.max()) < W * cap and int(slot.min()) >= cap          # aliased, never out of range
+
+
+def test_trainer_check_errors_raises_on_bad_ids():
+    from recommendit_amd import TwoTowerModel
+    from recommendit_amd.trainer import HipBPRTrainer
+    m = TwoTowerModel(50, 60, embed_dim=64, hidden_dim=128, dropout=0.0)
+    m.train()
+    tr = HipBPRTrainer(m, 32, loss_mode="sampled", table_opt="sparse")
+    g = torch.zeros(64, 18, device="cuda")
+    tr.step(torch.randint(1, 51, (32,), device="cuda"), torch.randint(1, 61, (64,), device="cuda"), g)
+    tr.check_errors()                                                   # clean step: nothing raised
+    bad = torch.randint(1, 61, (64,), device="cuda"); bad[5] = 10_000
+    tr.step(torch.randint(1, 51, (32,), device="cuda"), bad, g)
+    with pytest.raises(RuntimeError, match="outside its embedding table"):
+        tr.check_errors()
+    tr.check_errors()                                                   # the word was cleared

@@ -147,3 +147,50 @@ def test_batched_run_evaluate_equals_per_user_protocol(tmp_path):
     for k in (5, 10, 20):
         assert abs(res[f"ndcg@{k}"] - M.mean_ndcg(recs, truth, k)) < 1e-12
     assert 0 < res["coverage"] <= 1
+
+
+def test_graph_replay_survives_scratch_growth_and_state_changes(tmp_path):
+    """a graph captured for a single request bakes in handle-owned scratch pointers; a later, larger
+    eager batch frees and re-allocates them.  Order exercised here: graph(1) FIRST (small scratch), then an eager batch of
+    256, then graph(1) again -- must equal the eager result; likewise after nprobe and feature-table changes."""
+    from recommendit_amd import FAISSIndex, LightGBMRanker, TwoTowerModel
+    from recommendit_amd.recommender import GpuFeatureStore, GpuRecommendationPipeline, feature_columns
+    from recommendit_amd import _lib as L
+    nu, ni, d, H = 400, 6000, 64, 128
+    sd = fx.make_state(nu, ni, d, H, seed=3)
+    model = TwoTowerModel(nu, ni, d, H)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    rng = np.random.RandomState(4)
+    item_ids = list(range(1, ni + 1))
+    genres = (rng.rand(ni, 18) < 0.15).astype(np.float32)
+    E = model.get_item_embeddings(item_ids, genres)
+    index = FAISSIndex(embed_dim=d, n_lists=16, n_probe=4)
+    index.build_ivf_index(E, item_ids)
+    forest = G.random_forest_model(80, 31, 50, seed=6, names=feature_columns())
+    p = tmp_path / "r.lgbm"
+    p.write_text(G.write_text_model(forest))
+    ranker = LightGBMRanker.load(str(p))
+    store = GpuFeatureStore(nu, ni)
+    ut = store.user.copy(); it = store.item.copy()
+    ut[1:, :6] = rng.rand(nu, 6); ut[1:, 6:] = rng.rand(nu, 18)
+    it[1:, :5] = rng.rand(ni, 5); it[1:, 5:] = genres
+    store.load_arrays(ut, it)
+    pipe = GpuRecommendationPipeline(model, index, ranker, store, top_k_candidates=300, top_k_results=10)
+
+    def same(u):
+        g = pipe.get_recommendations(u, graph=True)
+        e = pipe.get_recommendations(u)
+        assert g == e and len(g) == 10
+
+    same(7)                                               # capture with single-request scratch
+    gen0 = L.lib().rihip_scratch_generation()
+    big = pipe.recommend_batch(list(range(1, 257)))       # grows count / fcand / the forest's partial sums
+    torch.cuda.synchronize()
+    assert L.lib().rihip_scratch_generation() != gen0     # the growth was seen
+    same(7); same(300)
+    assert pipe.recommend_batch([7], graph=True)[0][0].tolist() == big[0][6].tolist()
+    index.set_n_probe(9)                                  # a stale nprobe must not stay baked in
+    same(7)
+    it2 = it.copy(); it2[1:, :5] = rng.rand(ni, 5)        # reloaded feature tables: new device tensors
+    store.load_arrays(ut, it2)
+    same(7)
