@@ -6,5 +6,6 @@ Same names as the reference's ``src/models/__init__.py:1-3`` so callers switch w
 from .two_tower import ItemTower, TwoTowerModel, UserTower, N_GENRES  # noqa: F401
 from .faiss_index import FAISSIndex  # noqa: F401
 from .ranker import LightGBMRanker  # noqa: F401
+from ._lib import have_gpu  # noqa: F401  (the switch a caller guards the swap with: INTEGRATION.md §1)
 
-__all__ = ["TwoTowerModel", "UserTower", "ItemTower", "FAISSIndex", "LightGBMRanker", "N_GENRES"]
+__all__ = ["TwoTowerModel", "UserTower", "ItemTower", "FAISSIndex", "LightGBMRanker", "N_GENRES", "have_gpu"]

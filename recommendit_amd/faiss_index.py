@@ -260,8 +260,24 @@ class FAISSIndex:
             if obj.exact:
                 obj.build_from_device(x_dev, ids)
             else:
-                obj.n_lists = f["nlist"]
-                obj.build_from_device(x_dev, ids, centroids=f["centroids"], assign=f["assign"])
+                nlist, n = int(f["nlist"]), int(f["ntotal"])
+                max_lists = 2048      # csrc/ip_index.h NLIST_MAX (probe bitset of the list-major scan)
+                if nlist > max_lists:
+                    raise faiss_io.FaissFormatError(
+                        f"{load_path}: IndexIVFFlat with nlist={nlist} > {max_lists} lists is not supported by the HIP index")
+                if nlist > n:
+                    # more lists than vectors (faiss allows it; every search then probes mostly empty lists): serve the
+                    # file's vectors exactly instead of failing
+                    logger.warning("%s: nlist=%d > ntotal=%d, loading as a flat (exact) index", load_path, nlist, n)
+                    obj.exact = True
+                    obj.build_from_device(x_dev, ids)
+                else:
+                    obj.n_lists = nlist
+                    obj.build_from_device(x_dev, ids, centroids=f["centroids"], assign=f["assign"])
+                    # the sidecar's n_probe is what the reference restores (faiss_index.py:199-201); a file written by
+                    # faiss itself carries its own nprobe, used only when the sidecar has none
+                    if meta.get("n_probe") is None and f.get("nprobe"):
+                        obj.set_n_probe(int(f["nprobe"]))
             obj._item_id_to_faiss_idx = meta["item_id_to_faiss_idx"]
             return obj
         h = C.c_void_p()

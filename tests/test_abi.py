@@ -52,3 +52,10 @@ def test_no_cpu_fallback_without_gpu():
 def test_product_never_imports_oracle():
     for f in (ROOT / "recommendit_amd").glob("*.py"):
         assert "oracle" not in f.read_text().replace("SURVEY", ""), f
+
+
+def test_integration_guard_is_the_device_not_the_import():
+    """the package imports on a GPU-less host, so the swap must test have_gpu()"""
+    import recommendit_amd
+    import torch
+    assert recommendit_amd.have_gpu() == torch.cuda.is_available()

@@ -257,3 +257,63 @@ def test_faiss_file_interop(tmp_path):
     ex2 = FAISSIndex.load(str(tmp_path / "c.index"))
     assert ex2.exact and not ex2.index.is_ivf
     np.testing.assert_array_equal(ex2.batch_search(Q, k=k)[1], ex.batch_search(Q, k=k)[1])
+
+
+def test_faiss_file_load_guards(tmp_path):
+    """IndexIVFFlat files the HIP index cannot hold as lists -- more lists than vectors -> served as a flat
+    (exact) index; more than 2048 lists -> a FaissFormatError, not a bare assert; rank_topk serves k up to 16384."""
+    import pickle
+    from recommendit_amd import FAISSIndex, faiss_io
+    rng = np.random.RandomState(41)
+    d = 32
+
+    def write(name, n, nlist):
+        X = fx.unit_rows(rng, n, d)
+        C = fx.unit_rows(rng, nlist, d)
+        a = R.ivf_assign(X, C)
+        faiss_io.write_ivf_flat(str(tmp_path / f"{name}.index"), X, C, a, nprobe=4)
+        ids = np.arange(10, 10 + n)
+        with open(tmp_path / f"{name}.meta.pkl", "wb") as f:
+            pickle.dump({"item_ids": ids, "item_id_to_faiss_idx": {int(i): j for j, i in enumerate(ids)},
+                         "embed_dim": d, "n_lists": nlist, "n_probe": 4}, f)
+        return X, ids
+
+    X, ids = write("tiny", 50, 80)                       # nlist > ntotal
+    idx = FAISSIndex.load(str(tmp_path / "tiny.index"))
+    assert idx.exact and idx.index.ntotal == 50
+    Q = fx.unit_rows(rng, 5, d)
+    sc, got = idx.batch_search(Q, k=10)
+    o_s, o_r = R.topk_ip_exact(Q, X, 10)
+    np.testing.assert_allclose(sc, o_s, atol=TOL)
+    assert (got == ids[o_r]).mean() > 0.95
+    write("wide", 5000, 2500)                            # nlist > 2048
+    with pytest.raises(faiss_io.FaissFormatError, match="2048"):
+        FAISSIndex.load(str(tmp_path / "wide.index"))
+
+
+def test_rank_topk_large_candidate_sets_and_nan_scores():
+    """rihip_rank_topk (DataFrame.nlargest at recommender.py:346) up to the index's K_MAX = 16384 candidates; NaN ranker
+    scores never outrank a number, padded candidates come last"""
+    from recommendit_amd import _lib as L
+    lib, dev = L.lib(), L.device()
+    rng = np.random.RandomState(5)
+    for nq, kc, k in ((3, 16384, 50), (2, 9000, 9000), (4, 500, 20)):
+        s = rng.randn(nq, kc)
+        s[:, 7] = np.nan; s[0, 11] = np.inf; s[1, 13] = -np.inf
+        cand = np.arange(nq * kc, dtype=np.int64).reshape(nq, kc) + 5
+        cand[:, kc - 3:] = -1
+        rs = rng.rand(nq, kc).astype(np.float32)
+        sd, cd, rd = (torch.from_numpy(x).to(dev) for x in (s, cand, rs))
+        ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        top = torch.empty((nq, k), dtype=torch.float64, device=dev)
+        trs = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        L.check(lib.rihip_rank_topk(sd.data_ptr(), cd.data_ptr(), rd.data_ptr(), nq, kc, k, ids.data_ptr(), top.data_ptr(),
+                                    trs.data_ptr(), L.stream_ptr()), "rank_topk")
+        ids, top = ids.cpu().numpy(), top.cpu().numpy()
+        for q in range(nq):
+            key = np.where(cand[q] < 0, -np.inf, s[q])
+            cls = np.where(cand[q] < 0, 2, np.where(np.isnan(s[q]), 1, 0))       # numbers, then NaN, then padding
+            order = np.lexsort((np.arange(kc), -np.nan_to_num(key, nan=0.0, posinf=1e308, neginf=-1e308), cls))[:k]
+            np.testing.assert_array_equal(ids[q], cand[q][order])
+            if k < kc - 4:
+                assert not np.isnan(top[q]).any()

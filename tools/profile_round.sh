@@ -4,7 +4,8 @@
 #   stats   : rocprofv3 --kernel-trace --stats of the default bench command
 #   fetch/write : HBM traffic of the headline step (separate --pmc passes, as MI355X_MICROARCH.md prescribes)
 #   pmc_*   : SQ wave-state / MFMA-busy / LDS / traffic counters of the headline, tower, retrieval and serve kernels
-# Every rocprofv3 line runs the python program directly (no env/bash hop) and never mixes --pmc with trace domains.
+# Every rocprofv3 line runs the python program directly (no env/bash hop).  The counter passes use --kernel-trace --pmc
+# (kernel dispatch records are what carries the counters) and never add -s/-r or the hip/hsa/memory-copy/marker domains.
 set -e
 TAG=${1:-r02}
 PART=${2:-all}
