@@ -155,14 +155,17 @@ __global__ void head_flags_kernel(const int64_t* __restrict__ sorted, int64_t n,
   if (i < n) flags[i] = (i == 0 || sorted[i] != sorted[i - 1]) ? 1 : 0;
 }
 // seg[i] = inclusive scan of head flags (1-based segment number); write segment starts + unique ids
+// an id outside [0, n_rows) (already flagged by the tower forward's err word) becomes the padding row 0: its gradient is
+// dropped and the row-sparse Adam never touches memory outside the table
 __global__ void seg_starts_kernel(const int64_t* __restrict__ sorted, const int* __restrict__ seg, int64_t n,
-                                  int* seg_start, int64_t* uniq, int* n_unique) {
+                                  int64_t n_rows, int* seg_start, int64_t* uniq, int* n_unique) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int s = seg[i] - 1;
   if (i == 0 || seg[i] != seg[i - 1]) {
     seg_start[s] = (int)i;
-    uniq[s] = sorted[i];
+    const int64_t id = sorted[i];
+    uniq[s] = (id >= 0 && (n_rows <= 0 || id < n_rows)) ? id : 0;
   }
   if (i == n - 1) {
     seg_start[s + 1] = (int)n;
@@ -590,7 +593,7 @@ extern "C" int rihip_rows_group(const int64_t* ids, int64_t B, int d, int64_t n_
   RIHIP_CHECK_LAUNCH();
   tb = ws.temp_bytes;
   RIHIP_CHECK_HIP(rocprim::inclusive_scan(ws.temp, tb, ws.flags, ws.seg, (size_t)B, rocprim::plus<int>(), st));
-  hipLaunchKernelGGL(seg_starts_kernel, dim3(nb), dim3(256), 0, st, ws.keys_out, ws.seg, B, ws.seg_start, uniq,
+  hipLaunchKernelGGL(seg_starts_kernel, dim3(nb), dim3(256), 0, st, ws.keys_out, ws.seg, B, n_rows, ws.seg_start, uniq,
                      ws.n_unique);
   RIHIP_CHECK_LAUNCH();
   return RIHIP_OK;
