@@ -56,8 +56,11 @@ int rihip_device_arch(char* buf, int buf_len);
  * MFMA-fragment-major copy of W1/W2 rebuilt each call (coalesced weight loads).
  * seed_step_dev (nullable): device int64 mixed into the dropout seed, so a captured hipGraph draws a fresh
  * mask on every replay (the counter is advanced by rihip_adam_hyper_step).
- * Supported (d,hidden): see rihip_tower_supported. */
+ * Shapes: the reference takes any (embed_dim, hidden_dim) (two_tower.py:80-95).  rihip_tower_shape_ok(d, hidden) = 1 for
+ * every pair of multiples of 16 up to 256; rihip_tower_supported(d, hidden) = 1 for the pairs with tuned template
+ * instantiations (the fast path) -- every other pair runs the runtime-shape kernels of csrc/tower_generic.hip. */
 int rihip_tower_supported(int d, int hidden);
+int rihip_tower_shape_ok(int d, int hidden);
 int64_t rihip_tower_forward_workspace_floats(int d, int hidden, int item);
 int rihip_tower_forward(const float* table, int64_t n_rows, const int64_t* ids, const float* genres, int64_t B,
                         int d, int hidden, const float* W1, const float* b1, const float* W2, const float* b2,
@@ -290,7 +293,9 @@ void rihip_free(void* p);
  * search: Q device [nq,d]; out_scores f32[nq,k] descending, -inf padded; out_rows i64[nq,k]
  * row numbers in insertion order, -1 padded (faiss convention kept by faiss_index.py:148-152).
  * Exact for a flat index (ties -> lowest row); synchronises the stream once per 4096 queries
- * (exactness check).  k <= rihip_ip_index_max_k() (16384).  d in {32,64,128}.  nlist <= 2048.
+ * (exactness check).  k <= rihip_ip_index_max_k() (16384).  1 <= d <= 128: the handle zero-pads rows, queries and
+ * centroids to its kernel width (32 / 64 / 128), which changes no inner product; every array that crosses the ABI is
+ * [*, d] at the caller's width.  nlist <= 2048.
  * IVF (faiss_index.py:68-74): train_ivf = k-means (Lloyd, IP assignment, mean update, empty lists keep their
  * centroid) from seeded rows, then list-contiguous layout; train_ivf_from = the same from caller-supplied
  * initial centroids (host [nlist,d]; n_iter = 0 partitions by them as they are); set_ivf injects centroids AND

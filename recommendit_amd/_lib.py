@@ -29,6 +29,7 @@ SIGNATURES = {
     "rihip_scratch_generation": (C.c_uint64, []),
     "rihip_device_arch": (C.c_int, [C.c_char_p, C.c_int]),
     "rihip_tower_supported": (C.c_int, [C.c_int, C.c_int]),
+    "rihip_tower_shape_ok": (C.c_int, [C.c_int, C.c_int]),
     "rihip_tower_forward_workspace_floats": (c_i64, [C.c_int, C.c_int, C.c_int]),
     "rihip_tower_forward": (C.c_int, [vp, c_i64, vp, vp, c_i64, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, C.c_float,
                                       C.c_uint64, c_i64, vp, vp, vp, vp, vp, vp, vp]),

@@ -30,7 +30,9 @@ struct DevBuf {
 };
 
 struct IpIndex {
-  int d = 0;
+  int d = 0;             // kernel width: 32 / 64 / 128 (the template instantiations)
+  int du = 0;            // caller's embedding width (1 .. 128): rows are zero-padded to d inside the handle, which
+                         // changes no inner product (the extra terms are exact zeros of the fmaf chain)
   int64_t N = 0;         // real vectors
   float* X = nullptr;    // brute force: [N,d]; IVF: [Np,d] list-ordered, zero-padded to 64-row granules
   __bf16* Xb = nullptr;  // bf16 copy of X for the filter pass (flat index, N > 4*SAMPLE)
@@ -52,7 +54,7 @@ struct IpIndex {
   DevBuf<uint64_t> cand, scand, fcand, seg;   // seg: per (query, corpus split) survivor segments of the bf16 filter
   DevBuf<int> seg_cnt;
   DevBuf<int> count, fail_flags, fail_list, n_fail, fcount;
-  DevBuf<float> thr, thr2, fQ;
+  DevBuf<float> thr, thr2, fQ, qpad;    // qpad: queries / rows zero-padded from du to d columns
   DevBuf<float> coarse;                                    // IVF: coarse scores [nq,nlist]
   DevBuf<int> probe_list, list_q, list_cnt, list_qoff, list_cur, work_off, plan;
   int* h_nfail = nullptr;  // pinned
@@ -65,6 +67,8 @@ inline void free_index_arrays(IpIndex* h) {
   h->N = 0; h->Np = 0; h->ivf = false; h->nlist = 0; h->list_len.clear();
 }
 
+// zero-pad n rows of width du (device) into rows of width d (device)
+int pad_rows(const float* src, int64_t n, int du, int d, float* dst, hipStream_t st);
 // flat index: (re)build the bf16 filter copy and the row-norm bound (topk.hip)
 int prepare_flat(IpIndex* h, hipStream_t st);
 // upload the per-list offsets/lengths the list-major scan reads (from the host copy list_len; ivf.hip)

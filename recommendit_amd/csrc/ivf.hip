@@ -325,6 +325,18 @@ int derive_ivf_aux(IpIndex* h, hipStream_t st) {
 }
 }  // namespace rihip_index
 
+namespace {
+// host-side column padding / slicing between the caller's width du and the kernel width d
+std::vector<float> pad_host(const float* src, int64_t n, int du, int d) {
+  std::vector<float> out((size_t)n * d, 0.f);
+  for (int64_t i = 0; i < n; ++i) memcpy(out.data() + (size_t)i * d, src + (size_t)i * du, sizeof(float) * du);
+  return out;
+}
+void unpad_host(const float* src, int64_t n, int d, int du, float* dst) {
+  for (int64_t i = 0; i < n; ++i) memmove(dst + (size_t)i * du, src + (size_t)i * d, sizeof(float) * du);
+}
+}  // namespace
+
 // k-means from `nlist` distinct seed rows picked by a seeded generator over a strided lattice.  Deterministic given seed.
 extern "C" int rihip_ip_index_train_ivf(void* handle, int nlist, int n_iter, uint64_t seed, void* stream) {
   IpIndex* h = (IpIndex*)handle;
@@ -356,7 +368,8 @@ extern "C" int rihip_ip_index_train_ivf_from(void* handle, int nlist, int n_iter
   hipStream_t st = (hipStream_t)stream;
   float* C = nullptr;
   HIPCHK(hipMalloc((void**)&C, sizeof(float) * (size_t)nlist * h->d));
-  if (hipMemcpyAsync(C, init_centroids, sizeof(float) * (size_t)nlist * h->d, hipMemcpyHostToDevice, st) != hipSuccess ||
+  const std::vector<float> cp = pad_host(init_centroids, nlist, h->du, h->d);
+  if (hipMemcpyAsync(C, cp.data(), sizeof(float) * (size_t)nlist * h->d, hipMemcpyHostToDevice, st) != hipSuccess ||
       hipStreamSynchronize(st) != hipSuccess) {
     hipFree(C);
     rihip_set_error("ip_index_train_ivf_from: centroid upload failed");
@@ -378,8 +391,9 @@ extern "C" int rihip_ip_index_set_ivf(void* handle, int nlist, const float* cent
   float* C = nullptr;
   int* a_dev = nullptr;
   HIPCHK(hipMalloc((void**)&C, sizeof(float) * (size_t)nlist * h->d));
+  const std::vector<float> cp = pad_host(centroids, nlist, h->du, h->d);
   if (hipMalloc((void**)&a_dev, sizeof(int) * h->N) != hipSuccess ||
-      hipMemcpyAsync(C, centroids, sizeof(float) * (size_t)nlist * h->d, hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(C, cp.data(), sizeof(float) * (size_t)nlist * h->d, hipMemcpyHostToDevice, st) != hipSuccess ||
       hipMemcpyAsync(a_dev, assign, sizeof(int) * h->N, hipMemcpyHostToDevice, st) != hipSuccess ||
       hipStreamSynchronize(st) != hipSuccess) {
     hipFree(C); hipFree(a_dev);
@@ -397,7 +411,11 @@ extern "C" int rihip_ip_index_nlist(void* handle) { return handle ? ((IpIndex*)h
 extern "C" int rihip_ip_index_get_ivf(void* handle, float* centroids, int32_t* assign) {
   IpIndex* h = (IpIndex*)handle;
   RIHIP_REQUIRE(h && h->ivf, RIHIP_ERR_STATE, "ip_index_get_ivf: not an IVF index");
-  if (centroids) HIPCHK(hipMemcpy(centroids, h->C, sizeof(float) * (size_t)h->nlist * h->d, hipMemcpyDeviceToHost));
+  if (centroids) {
+    std::vector<float> c((size_t)h->nlist * h->d);
+    HIPCHK(hipMemcpy(c.data(), h->C, sizeof(float) * c.size(), hipMemcpyDeviceToHost));
+    unpad_host(c.data(), h->nlist, h->d, h->du, centroids);
+  }
   if (assign) {
     std::vector<int64_t> rid(h->Np);
     std::vector<int> tl(h->Np / TR);
@@ -414,14 +432,21 @@ extern "C" int rihip_ip_index_reconstruct(void* handle, float* out) {
   IpIndex* h = (IpIndex*)handle;
   RIHIP_REQUIRE(h && h->X && out, RIHIP_ERR_STATE, "ip_index_reconstruct: empty index or null output");
   const size_t bytes = sizeof(float) * (size_t)h->N * h->d;
-  if (!h->ivf) { HIPCHK(hipMemcpy(out, h->X, bytes, hipMemcpyDeviceToHost)); return RIHIP_OK; }
-  float* tmp = nullptr;
-  HIPCHK(hipMalloc((void**)&tmp, bytes));
-  const int64_t tot = h->Np * (h->d / 4);
-  hipLaunchKernelGGL(ivf_unpermute_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, 0, h->X, h->d, h->row_ids, h->Np, tmp);
-  hipError_t e = hipMemcpy(out, tmp, bytes, hipMemcpyDeviceToHost);
-  hipFree(tmp);
-  HIPCHK(e);
+  std::vector<float> host;
+  float* dst = out;
+  if (h->du != h->d) { host.resize((size_t)h->N * h->d); dst = host.data(); }
+  if (!h->ivf) {
+    HIPCHK(hipMemcpy(dst, h->X, bytes, hipMemcpyDeviceToHost));
+  } else {
+    float* tmp = nullptr;
+    HIPCHK(hipMalloc((void**)&tmp, bytes));
+    const int64_t tot = h->Np * (h->d / 4);
+    hipLaunchKernelGGL(ivf_unpermute_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, 0, h->X, h->d, h->row_ids, h->Np, tmp);
+    hipError_t e = hipMemcpy(dst, tmp, bytes, hipMemcpyDeviceToHost);
+    hipFree(tmp);
+    HIPCHK(e);
+  }
+  if (h->du != h->d) unpad_host(host.data(), h->N, h->d, h->du, out);
   return RIHIP_OK;
 }
 
@@ -430,6 +455,11 @@ extern "C" int rihip_ip_index_assign(void* handle, const float* X, int64_t n, in
   IpIndex* h = (IpIndex*)handle;
   RIHIP_REQUIRE(h && h->ivf && h->C, RIHIP_ERR_STATE, "ip_index_assign: not an IVF index");
   RIHIP_REQUIRE(X && assign && n > 0, RIHIP_ERR_ARG, "ip_index_assign: bad arguments");
+  if (h->du != h->d) {
+    RCCHK(h->qpad.reserve(n * h->d));
+    RCCHK(pad_rows(X, n, h->du, h->d, h->qpad.p, (hipStream_t)stream));
+    X = h->qpad.p;
+  }
   RIHIP_REQUIRE((reinterpret_cast<uintptr_t>(X) & 15) == 0, RIHIP_ERR_ARG, "ip_index_assign: X must be 16-byte aligned");
   return launch_assign(h->d, X, n, h->C, h->nlist, assign, (hipStream_t)stream);
 }
@@ -444,7 +474,7 @@ extern "C" int rihip_ip_index_save(void* handle, const char* path) {
   std::vector<float> X((size_t)rows * h->d);
   hipMemcpy(X.data(), h->X, sizeof(float) * X.size(), hipMemcpyDeviceToHost);
   const char magic[8] = {'R', 'I', 'H', 'I', 'P', 'I', 'D', 'X'};
-  int64_t hdr[8] = {1, h->d, h->N, h->ivf ? 1 : 0, h->nlist, h->nprobe, h->Np, 0};
+  int64_t hdr[8] = {1, h->d, h->N, h->ivf ? 1 : 0, h->nlist, h->nprobe, h->Np, h->du};   // hdr[7]: caller's width (0 = d)
   fwrite(magic, 1, 8, f); fwrite(hdr, sizeof(int64_t), 8, f); fwrite(X.data(), sizeof(float), X.size(), f);
   if (h->ivf) {
     std::vector<float> C((size_t)h->nlist * h->d); std::vector<int> tl(h->Np / TR); std::vector<int64_t> rid(h->Np);
@@ -469,7 +499,7 @@ extern "C" int rihip_ip_index_load(const char* path, void** handle) {
     fclose(f); rihip_set_error("ip_index_load: %s is not a RIHIPIDX v1 file", path); return RIHIP_ERR_IO;
   }
   IpIndex* h = new IpIndex();
-  h->d = (int)hdr[1]; h->N = hdr[2]; h->ivf = hdr[3] != 0; h->nlist = (int)hdr[4]; h->nprobe = (int)hdr[5]; h->Np = hdr[6];
+  h->d = (int)hdr[1]; h->du = hdr[7] > 0 ? (int)hdr[7] : h->d; h->N = hdr[2]; h->ivf = hdr[3] != 0; h->nlist = (int)hdr[4]; h->nprobe = (int)hdr[5]; h->Np = hdr[6];
   const int64_t rows = h->ivf ? h->Np : h->N;
   std::vector<float> X((size_t)rows * h->d);
   bool ok = fread(X.data(), sizeof(float), X.size(), f) == X.size();

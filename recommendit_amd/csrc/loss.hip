@@ -16,6 +16,9 @@
 
 void rihip_launch_sweep_bf16x3(int d, bool mode_user, const SweepArgs& a, dim3 grid, hipStream_t st);
 void rihip_launch_sweep_x6(int d, bool mode_user, const SweepArgs& a, dim3 grid, int nw, hipStream_t st);
+// loss_generic.hip: runtime-width sweep (any embed_dim multiple of 16 up to 256) behind the tuned instantiations
+bool rihip_inbatch_generic_ok(int d);
+void rihip_launch_sweep_generic(int d, bool mode_user, const SweepArgs& a, int nsplit_slots, hipStream_t st);
 void rihip_launch_gt_x6(int d, const SweepArgs& a, dim3 grid, int nw, hipStream_t st);
 
 namespace {
@@ -616,7 +619,11 @@ extern "C" int rihip_inbatch_sweep(int mode_user, const float* owners, int64_t n
                                    const float* swept, int64_t n_swept, int64_t swept_goff, int d, const float* pos,
                                    const float* r_in, int64_t n_global, float* d_owner, float* r_out,
                                    double* loss_part, float* workspace, int precision, void* stream) {
-  RIHIP_REQUIRE(d == 32 || d == 64 || d == 128, RIHIP_ERR_SHAPE, "inbatch_sweep: unsupported embed_dim=%d", d);
+  const bool tuned = d == 32 || d == 64 || d == 128;
+  RIHIP_REQUIRE(tuned || rihip_inbatch_generic_ok(d), RIHIP_ERR_SHAPE,
+                "inbatch_sweep: unsupported embed_dim=%d (multiples of 16 up to 256)", d);
+  RIHIP_REQUIRE(tuned || precision == 0, RIHIP_ERR_SHAPE,
+                "inbatch_sweep: the split-bf16 modes exist for embed_dim 32/64/128 only (embed_dim=%d)", d);
   RIHIP_REQUIRE(precision >= 0 && precision <= 2, RIHIP_ERR_ARG,
                 "inbatch_sweep: precision=%d (0=f32 MFMA, 1=bf16x3, 2=bf16x6)", precision);
   RIHIP_REQUIRE(owners && swept && pos && d_owner, RIHIP_ERR_ARG, "inbatch_sweep: null pointer");
@@ -638,6 +645,11 @@ extern "C" int rihip_inbatch_sweep(int mode_user, const float* owners, int64_t n
   a.r_part = workspace ? workspace + (size_t)a.nsplit * n_owner * d : nullptr;
   const dim3 grid((unsigned)((n_owner + nw * 32 - 1) / (nw * 32)), (unsigned)a.nsplit);
   hipStream_t st = (hipStream_t)stream;
+  if (!tuned) {   // runtime-width kernel: final results in one launch (it fills every loss slot of the tuned layout)
+    rihip_launch_sweep_generic(d, mode_user != 0, a, a.nsplit, st);
+    RIHIP_CHECK_LAUNCH();
+    return RIHIP_OK;
+  }
   if (precision == 1) rihip_launch_sweep_bf16x3(d, mode_user != 0, a, grid, st);
   else if (precision == 2) rihip_launch_sweep_x6(d, mode_user != 0, a, grid, nw, st);
   else if (d == 32) launch_sweep<32>(mode_user != 0, a, grid, nw, st);
@@ -663,7 +675,8 @@ extern "C" int rihip_inbatch_user_pass(const float* users, int64_t n_users, int6
                                        int64_t n_items, int64_t item_goff, int d, const float* pos, int64_t n_global,
                                        float* d_users, float* r_out, double* loss_part, float* workspace, float* gmat,
                                        int precision, void* stream) {
-  RIHIP_REQUIRE(d == 32 || d == 64 || d == 128, RIHIP_ERR_SHAPE, "inbatch_user_pass: unsupported embed_dim=%d", d);
+  RIHIP_REQUIRE(d == 32 || d == 64 || d == 128, RIHIP_ERR_SHAPE,
+                "inbatch_user_pass: the stored-G form exists for embed_dim 32/64/128 only (embed_dim=%d: use rihip_inbatch_sweep)", d);
   RIHIP_REQUIRE(users && items && pos && d_users && r_out && loss_part && gmat, RIHIP_ERR_ARG,
                 "inbatch_user_pass: null pointer");
   RIHIP_REQUIRE(precision == 0 || precision == 2, RIHIP_ERR_ARG,

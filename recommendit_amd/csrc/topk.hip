@@ -1710,11 +1710,28 @@ int prepare_flat(IpIndex* h, hipStream_t st) {
 }
 }  // namespace rihip_index
 
+namespace rihip_index {
+__global__ void pad_rows_kernel(const float* __restrict__ src, int64_t n, int du, int d, float* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * d) return;
+  const int64_t r = i / d;
+  const int k = (int)(i % d);
+  dst[i] = k < du ? src[r * du + k] : 0.f;
+}
+int pad_rows(const float* src, int64_t n, int du, int d, float* dst, hipStream_t st) {
+  const int64_t tot = n * d;
+  hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, src, n, du, d, dst);
+  RIHIP_CHECK_LAUNCH();
+  return RIHIP_OK;
+}
+}  // namespace rihip_index
+
 extern "C" int rihip_ip_index_create(int d, void** handle) {
   RIHIP_REQUIRE(handle, RIHIP_ERR_ARG, "ip_index_create: null handle");
-  RIHIP_REQUIRE(d == 32 || d == 64 || d == 128, RIHIP_ERR_SHAPE, "ip_index_create: unsupported embed_dim=%d (32/64/128)", d);
+  RIHIP_REQUIRE(d >= 1 && d <= 128, RIHIP_ERR_SHAPE, "ip_index_create: unsupported embed_dim=%d (1..128)", d);
   IpIndex* h = new IpIndex();
-  h->d = d;
+  h->du = d;
+  h->d = d <= 32 ? 32 : (d <= 64 ? 64 : 128);   // the scan kernels are instantiated for these widths: rows are zero-padded
   *handle = h;
   return RIHIP_OK;
 }
@@ -1727,6 +1744,7 @@ extern "C" int rihip_ip_index_destroy(void* handle) {
   h->fail_list.release(); h->n_fail.release(); h->fcount.release(); h->thr.release(); h->thr2.release(); h->fQ.release();
   h->coarse.release(); h->probe_list.release(); h->list_q.release(); h->list_cnt.release(); h->list_qoff.release();
   h->list_cur.release(); h->work_off.release(); h->plan.release(); h->qnorm.release(); h->seg.release(); h->seg_cnt.release();
+  h->qpad.release();
   if (h->h_nfail) hipHostFree(h->h_nfail);
   delete h;
   return RIHIP_OK;
@@ -1738,8 +1756,24 @@ extern "C" int rihip_ip_index_set_vectors(void* handle, const float* X, int64_t 
   RIHIP_REQUIRE(h && X && N > 0 && N < (1ll << 31), RIHIP_ERR_ARG, "ip_index_set_vectors: bad arguments");
   free_index_arrays(h);
   HIPCHK(hipMalloc((void**)&h->X, sizeof(float) * (size_t)N * h->d));
-  HIPCHK(hipMemcpyAsync(h->X, X, sizeof(float) * (size_t)N * h->d, x_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
-                        (hipStream_t)stream));
+  if (h->du == h->d) {
+    HIPCHK(hipMemcpyAsync(h->X, X, sizeof(float) * (size_t)N * h->d, x_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                          (hipStream_t)stream));
+  } else {   // zero-pad the rows to the kernel width
+    const float* src = X;
+    float* tmp = nullptr;
+    if (!x_on_device) {
+      HIPCHK(hipMalloc((void**)&tmp, sizeof(float) * (size_t)N * h->du));
+      if (hipMemcpyAsync(tmp, X, sizeof(float) * (size_t)N * h->du, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) {
+        hipFree(tmp); rihip_set_error("ip_index_set_vectors: upload failed"); return RIHIP_ERR_HIP;
+      }
+      src = tmp;
+    }
+    const int rc = pad_rows(src, N, h->du, h->d, h->X, (hipStream_t)stream);
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    if (tmp) hipFree(tmp);
+    if (rc) return rc;
+  }
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   h->N = N;
   RCCHK(prepare_flat(h, (hipStream_t)stream));
@@ -1773,6 +1807,11 @@ extern "C" int rihip_ip_index_search(void* handle, const float* Q, int64_t nq, i
   RIHIP_REQUIRE(h && h->X && h->N > 0, RIHIP_ERR_STATE, "ip_index_search: index is empty");
   RIHIP_REQUIRE(Q && out_scores && out_rows && nq > 0, RIHIP_ERR_ARG, "ip_index_search: bad arguments");
   RIHIP_REQUIRE(k >= 1 && k <= K_MAX, RIHIP_ERR_ARG, "ip_index_search: k=%d outside [1,%d]", k, K_MAX);
+  if (h->du != h->d) {   // zero-pad the queries to the kernel width (scratch of the handle)
+    RCCHK(h->qpad.reserve(nq * h->d));
+    RCCHK(pad_rows(Q, nq, h->du, h->d, h->qpad.p, (hipStream_t)stream));
+    Q = h->qpad.p;
+  }
   RIHIP_REQUIRE((reinterpret_cast<uintptr_t>(Q) & 15) == 0, RIHIP_ERR_ARG, "ip_index_search: Q must be 16-byte aligned");
   const int64_t CH = 4096;  // queries per internal pass (bounds scratch)
   for (int64_t q0 = 0; q0 < nq; q0 += CH) {

@@ -733,6 +733,16 @@ extern "C" int rihip_tower_supported(int d, int hidden) {
          (d == 64 && hidden == 64) || (d == 32 && hidden == 128);
 }
 
+// tower_generic.hip: runtime-shape kernels behind the tuned instantiations
+bool rihip_tower_generic_ok(int d, int hidden);
+void rihip_launch_tower_fwd_generic(int d, int hidden, bool item, const TowerFwdArgs& a, hipStream_t st);
+int rihip_launch_tower_bwd_generic(int d, int hidden, bool item, const TowerBwdArgs& a, float* act, int max_slabs,
+                                   hipStream_t st, hipEvent_t dx_event);
+
+extern "C" int rihip_tower_shape_ok(int d, int hidden) {
+  return (rihip_tower_supported(d, hidden) || rihip_tower_generic_ok(d, hidden)) ? 1 : 0;
+}
+
 #define DISPATCH_DH(FN, ...)                                         \
   if (d == 32 && hidden == 64) FN<32, 64>(__VA_ARGS__);              \
   else if (d == 64 && hidden == 128) FN<64, 128>(__VA_ARGS__);       \
@@ -745,8 +755,8 @@ extern "C" int rihip_tower_forward(const float* table, int64_t n_rows, const int
                                    const float* b2, int training, float dropout_p, uint64_t seed, int64_t row0,
                                    float* out, float* hid, float* denom, int* err_flag, float* workspace,
                                    const int64_t* seed_step_dev, void* stream) {
-  RIHIP_REQUIRE(rihip_tower_supported(d, hidden), RIHIP_ERR_SHAPE,
-                "tower_forward: unsupported (embed_dim=%d, hidden_dim=%d)", d, hidden);
+  RIHIP_REQUIRE(rihip_tower_shape_ok(d, hidden), RIHIP_ERR_SHAPE,
+                "tower_forward: unsupported (embed_dim=%d, hidden_dim=%d): both must be multiples of 16 up to 256", d, hidden);
   RIHIP_REQUIRE(B >= 0 && n_rows > 0, RIHIP_ERR_ARG, "tower_forward: bad sizes B=%lld n_rows=%lld", (long long)B,
                 (long long)n_rows);
   if (B == 0) return RIHIP_OK;  // empty batch: nothing to read or write
@@ -767,6 +777,11 @@ extern "C" int rihip_tower_forward(const float* table, int64_t n_rows, const int
   const bool item = genres != nullptr;
   hipStream_t st = (hipStream_t)stream;
   a.W1p = nullptr; a.W2p = nullptr;
+  if (!rihip_tower_supported(d, hidden)) {   // no tuned instantiation for this pair: the runtime-shape kernel
+    rihip_launch_tower_fwd_generic(d, hidden, item, a, st);
+    RIHIP_CHECK_LAUNCH();
+    return RIHIP_OK;
+  }
   {  // wave-per-32-rows kernel (tower2.hip): weights in LDS, activations in registers, no barrier in the row loop
     const char* ev = getenv("RIHIP_TOWER_FWD");  // 1: 64-row-tile kernel, 3: wave-per-32-rows kernel at any size (tests)
     const int which = ev ? atoi(ev) : 2;
@@ -851,8 +866,8 @@ extern "C" int rihip_tower_backward_partial(const float* table, int64_t n_rows, 
                                             const float* grad_out, const float* out, const float* denom,
                                             const float* hid, float dropout_scale, float* dX, float* workspace,
                                             void* stream, void* dx_event, int* n_slabs) {
-  RIHIP_REQUIRE(rihip_tower_supported(d, hidden), RIHIP_ERR_SHAPE,
-                "tower_backward: unsupported (embed_dim=%d, hidden_dim=%d)", d, hidden);
+  RIHIP_REQUIRE(rihip_tower_shape_ok(d, hidden), RIHIP_ERR_SHAPE,
+                "tower_backward: unsupported (embed_dim=%d, hidden_dim=%d): both must be multiples of 16 up to 256", d, hidden);
   RIHIP_REQUIRE(n_slabs, RIHIP_ERR_ARG, "tower_backward: null pointer");
   *n_slabs = 0;
   if (B <= 0) return RIHIP_OK;
@@ -872,6 +887,14 @@ extern "C" int rihip_tower_backward_partial(const float* table, int64_t n_rows, 
   float* part = slab_part_of(workspace, B, P);
   float* act = part + (size_t)SLAB_GROUPS * P;
   int nslab = 0;
+  if (!rihip_tower_supported(d, hidden)) {   // runtime-shape kernels (same slab layout, one slab per batch split)
+    const int64_t nt32 = (B + 31) / 32;
+    nslab = rihip_launch_tower_bwd_generic(d, hidden, item, a, act, (int)(nt32 < RIHIP_NCU ? nt32 : RIHIP_NCU), st,
+                                           (hipEvent_t)dx_event);
+    RIHIP_CHECK_LAUNCH();
+    *n_slabs = nslab;
+    return RIHIP_OK;
+  }
   {  // two-kernel backward (tower2.hip) for chip-filling batches; 1 = the fused 64-row-tile kernel
     const char* ev = getenv("RIHIP_TOWER_BWD");
     const int which = ev ? atoi(ev) : 2;
@@ -959,11 +982,11 @@ extern "C" int rihip_tower_forward_pair(const rihip_tower_io* user, const rihip_
                                         int training, float dropout_p, int* err_flag, const int64_t* seed_step_dev,
                                         void* stream) {
   RIHIP_REQUIRE(user && item, RIHIP_ERR_ARG, "tower_forward_pair: null pointer");
-  RIHIP_REQUIRE(rihip_tower_supported(d, hidden), RIHIP_ERR_SHAPE,
+  RIHIP_REQUIRE(rihip_tower_shape_ok(d, hidden), RIHIP_ERR_SHAPE,
                 "tower_forward: unsupported (embed_dim=%d, hidden_dim=%d)", d, hidden);
   const rihip_tower_io* io[2] = {user, item};
   const char* ev = getenv("RIHIP_TOWER_FWD");
-  bool pair = user->B > 0 && item->B > 0 && user->B < 49152 && item->B < 49152 && !(ev && atoi(ev) == 3) &&
+  bool pair = rihip_tower_supported(d, hidden) && user->B > 0 && item->B > 0 && user->B < 49152 && item->B < 49152 && !(ev && atoi(ev) == 3) &&
               user->genres == nullptr && item->genres != nullptr && dropout_p >= 0.f && dropout_p < 1.f;
   for (int t = 0; t < 2 && pair; ++t)
     pair = io[t]->table && io[t]->ids && io[t]->W1 && io[t]->b1 && io[t]->W2 && io[t]->b2 && io[t]->out &&
@@ -1019,13 +1042,13 @@ extern "C" int rihip_tower_backward_partial_pair(const rihip_tower_io* user, con
                                                  float dropout_scale, void* stream, void* dx_event_user,
                                                  void* dx_event_item, int* n_slabs_user, int* n_slabs_item) {
   RIHIP_REQUIRE(user && item && n_slabs_user && n_slabs_item, RIHIP_ERR_ARG, "tower_backward_partial_pair: null pointer");
-  RIHIP_REQUIRE(rihip_tower_supported(d, hidden), RIHIP_ERR_SHAPE,
+  RIHIP_REQUIRE(rihip_tower_shape_ok(d, hidden), RIHIP_ERR_SHAPE,
                 "tower_backward: unsupported (embed_dim=%d, hidden_dim=%d)", d, hidden);
   const rihip_tower_io* io[2] = {user, item};
   int* ns[2] = {n_slabs_user, n_slabs_item};
   void* evs[2] = {dx_event_user, dx_event_item};
   const char* ev = getenv("RIHIP_TOWER_BWD");
-  bool pair = user->B > 0 && item->B > 0 && user->B < 49152 && item->B < 49152 && !(ev && atoi(ev) == 3) &&
+  bool pair = rihip_tower_supported(d, hidden) && user->B > 0 && item->B > 0 && user->B < 49152 && item->B < 49152 && !(ev && atoi(ev) == 3) &&
               user->genres == nullptr && item->genres != nullptr;
   for (int t = 0; t < 2 && pair; ++t)
     pair = io[t]->table && io[t]->ids && io[t]->W1 && io[t]->W2 && io[t]->grad_out && io[t]->out && io[t]->denom &&

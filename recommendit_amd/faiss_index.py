@@ -9,8 +9,8 @@ Index files: ``save(path)`` writes the library's own "RIHIPIDX" format by defaul
 ``IndexFlatIP`` file with ``format="faiss"``; ``load(path)`` sniffs the magic and reads either (faiss_io.py; the FAISS
 layout is restated from faiss 1.7.x and unverifiable offline: parity unpinned).  The k-means trainer is
 the library's own, so the IVF list membership of an index TRAINED here differs from one trained by faiss; an index
-LOADED from a faiss file keeps faiss's centroids and lists.  Limits the reference (faiss) does not have: embed_dim in
-{32, 64, 128}, n_lists <= 2048, k <= 16384 (INTEGRATION.md).
+LOADED from a faiss file keeps faiss's centroids and lists.  Limits the reference (faiss) does not have: embed_dim <= 128
+(any width: rows are zero-padded to the 32/64/128 kernel width inside the handle), n_lists <= 2048, k <= 16384.
 """
 from __future__ import annotations
 

@@ -238,7 +238,8 @@ class HipBPRTrainer:
             if store is None:
                 free_b = torch.cuda.mem_get_info(self.dev)[0]
                 store = self.inbatch_precision in (0, 2) and 4 * ng <= 0.5 * free_b
-            self.inbatch_store_g = bool(store) and self.inbatch_precision in (0, 2)
+            # (the stored-G passes exist for embed_dim 32/64/128; other widths run the runtime-width two-sweep kernel)
+            self.inbatch_store_g = bool(store) and self.inbatch_precision in (0, 2) and d in (32, 64, 128)
             if self.inbatch_store_g:
                 self.gmat = torch.empty((ng,), **f32)
             if self.dist:

@@ -58,8 +58,9 @@ class _TowerFn(torch.autograd.Function):
         H = W1c.shape[0]
         if g_d is not None and tuple(g_d.shape) != (B, N_GENRES):
             raise ValueError(f"genre_vectors must be [{B}, {N_GENRES}], got {tuple(g_d.shape)}")
-        if not lib.rihip_tower_supported(d, H):
-            raise RuntimeError(f"recommendit_amd: (embed_dim={d}, hidden_dim={H}) has no HIP kernel instantiation")
+        if not lib.rihip_tower_shape_ok(d, H):
+            raise RuntimeError(f"recommendit_amd: (embed_dim={d}, hidden_dim={H}) unsupported: both must be multiples of "
+                               "16 up to 256")
         out = torch.empty((B, d), dtype=torch.float32, device=dev)
         hid = torch.empty((B, H), dtype=torch.float32, device=dev)
         denom = torch.empty((B,), dtype=torch.float32, device=dev)
@@ -204,6 +205,8 @@ def inbatch_loss_and_grads(U: torch.Tensor, I: torch.Tensor, precision: int = 0,
     ng = lib.rihip_inbatch_gmat_floats(B, B)
     if store_g is None:
         store_g = 4 * ng <= (4 << 30)
+    if d not in (32, 64, 128):      # widths without a tuned instantiation: the runtime-width two-sweep kernel
+        store_g = False
     if store_g and precision in (0, 2):
         gm = torch.empty((ng,), dtype=torch.float32, device=dev)
         L.check(lib.rihip_inbatch_user_pass(Uc.data_ptr(), B, 0, Ic.data_ptr(), B, 0, d, posv.data_ptr(), B,
