@@ -120,6 +120,31 @@ int rihip_tower_backward_partial_pair(const rihip_tower_io* user, const rihip_to
                                       float dropout_scale, void* stream, void* dx_event_user, void* dx_event_item,
                                       int* n_slabs_user, int* n_slabs_item);
 
+/* The whole sampled-negative training step with the reference's optimiser (towers -> bpr_loss -> backward ->
+ * clip_grad_norm_ -> dense Adam + coupled L2 on the MLPs and BOTH tables: src/training/train_embeddings.py:178-195,
+ * :160-161) in ONE launch: a persistent grid walks the step behind three grid barriers (csrc/step_persistent.hip).  For
+ * the batch sizes the reference trains at (BATCH_SIZE = 1024, src/config.py:25; B <= 2048 here) a step is otherwise
+ * seven dependent launches.  Any (embed_dim, hidden_dim) of rihip_tower_shape_ok.  item.B = 2*user.B (pos || neg).
+ * grad_out / dX / out / hid / denom of both rihip_tower_io are scratch the step fills; bwd_workspace needs B*(d+hidden)
+ * floats.  dW1_u ... db2_i: the MLP gradient tensors (views of flat_g).  *_tab_g: dense table gradients, zero on entry and
+ * left zero.  step_dev / lr_dev / hyper_dev / coef / gnorm / loss as in rihip_clip_coef_step (the clock is advanced).
+ * barrier: 4 zero-initialised words owned by the caller for the life of the trainer.  Error bit 8 of *err_flag: the grid
+ * was not co-resident (another kernel held CUs) and the step was abandoned; bit 1: an id outside its table. */
+typedef struct rihip_step_args {
+  rihip_tower_io user, item;
+  float *dW1_u, *db1_u, *dW2_u, *db2_u, *dW1_i, *db1_i, *dW2_i, *db2_i;
+  float *flat_p, *flat_g, *flat_m, *flat_v; int64_t n_flat;
+  float *utab_g, *utab_m, *utab_v, *itab_g, *itab_m, *itab_v;
+  int d, hidden, training; float dropout_p;
+  float beta1, beta2, eps, weight_decay, max_norm;
+  const float* lr_dev; int64_t* step_dev; float* hyper_dev; float* coef; float* gnorm; float* loss; int* err_flag;
+  double* scratch_doubles; int64_t n_scratch_doubles;   /* >= rihip_bpr_step_scratch_doubles(B) */
+  unsigned* barrier;
+} rihip_step_args;
+int rihip_bpr_step_persistent_supported(int64_t B, int d, int hidden);
+int64_t rihip_bpr_step_scratch_doubles(int64_t B);
+int rihip_bpr_step_persistent(const rihip_step_args* a, void* stream);
+
 /* nn.Embedding backward (dense): grad_table[ids[b]] += dX[b]; row 0 (padding_idx, two_tower.py:27,54) and ids outside
  * [1, n_rows) are skipped.  Bitwise reproducible: every row receives its samples one after the other in batch order,
  * starting from its current contents (the float32 chain of index_add_ on a CPU) -- no floating-point atomics.

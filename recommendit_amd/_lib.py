@@ -118,6 +118,9 @@ SIGNATURES = {
                                          C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int), vp, vp]),
     "rihip_free": (None, [vp]),
     "rihip_sample_negatives": (C.c_int, [vp, c_i64, vp, c_i64, vp, c_i64, c_i64, C.c_uint64, C.c_int, vp, vp, vp]),
+    "rihip_bpr_step_persistent_supported": (C.c_int, [c_i64, C.c_int, C.c_int]),
+    "rihip_bpr_step_scratch_doubles": (c_i64, [c_i64]),
+    "rihip_bpr_step_persistent": (C.c_int, [vp, vp]),
     "rihip_rank_features_widths": (C.c_int, [vp, vp, vp]),
     "rihip_rank_topk": (C.c_int, [vp, vp, vp, c_i64, C.c_int, C.c_int, vp, vp, vp, vp]),
     "rihip_rank_features_build": (C.c_int, [vp, c_i64, vp, c_i64, vp, vp, c_i64, C.c_int, vp, C.c_int, vp, vp]),
@@ -158,6 +161,21 @@ class TowerIO(C.Structure):
                 ("W1", C.c_void_p), ("b1", C.c_void_p), ("W2", C.c_void_p), ("b2", C.c_void_p), ("seed", C.c_uint64),
                 ("row0", C.c_int64), ("out", C.c_void_p), ("hid", C.c_void_p), ("denom", C.c_void_p),
                 ("fwd_workspace", C.c_void_p), ("grad_out", C.c_void_p), ("dX", C.c_void_p), ("bwd_workspace", C.c_void_p)]
+
+
+class StepArgs(C.Structure):
+    """mirror of rihip_step_args (include/recommendit_hip.h): the one-launch sampled-negative training step"""
+    _fields_ = ([("user", TowerIO), ("item", TowerIO)]
+                + [(n, C.c_void_p) for n in ("dW1_u", "db1_u", "dW2_u", "db2_u", "dW1_i", "db1_i", "dW2_i", "db2_i",
+                                             "flat_p", "flat_g", "flat_m", "flat_v")]
+                + [("n_flat", C.c_int64)]
+                + [(n, C.c_void_p) for n in ("utab_g", "utab_m", "utab_v", "itab_g", "itab_m", "itab_v")]
+                + [("d", C.c_int), ("hidden", C.c_int), ("training", C.c_int), ("dropout_p", C.c_float),
+                   ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float),
+                   ("max_norm", C.c_float)]
+                + [(n, C.c_void_p) for n in ("lr_dev", "step_dev", "hyper_dev", "coef", "gnorm", "loss", "err_flag",
+                                             "scratch_doubles")]
+                + [("n_scratch_doubles", C.c_int64), ("barrier", C.c_void_p)])
 
 
 class RihipError(RuntimeError):

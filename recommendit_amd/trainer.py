@@ -113,14 +113,18 @@ class HipBPRTrainer:
                  betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = 1.0, loss_mode: str = "sampled",
                  table_opt: str = "dense", seed: int = 0, process_group=None, user_row_offset: int = 0,
                  inbatch_precision: int = 0, use_graph: bool = False, inbatch_store_g=None,
-                 distributed: bool = False, item_shard: str = "replicate", exchange_cap: Optional[int] = None):
+                 distributed: bool = False, item_shard: str = "replicate", exchange_cap: Optional[int] = None,
+                 persistent: Optional[bool] = None):
         """distributed=True (or a process_group): this trainer is one rank of a collective job -- EVERY rank of the
         group must construct it and call step() in lock-step.  Default False even when torch.distributed is
         initialised, so that a single-rank trainer inside a distributed program never issues collectives.
         item_shard="rows": model.item_tower.embedding holds only this rank's rows of the item table (see module doc).
         exchange_cap: send slots per peer of the row exchange (None = nI, the worst case).  A smaller capacity saves
         wire volume (W*cap*d*4 bytes per all-to-all) but a step that routes more than `cap` rows to one owner sets
-        error bit 2 (check_errors() raises)."""
+        error bit 2 (check_errors() raises).
+        persistent: run the sampled-negative step with the dense (reference) optimiser as ONE persistent launch
+        (csrc/step_persistent.hip: three grid barriers instead of seven dependent launches).  None = whenever the
+        shape allows it (single GPU, B <= 2048); False keeps the multi-launch path."""
         assert loss_mode in ("sampled", "inbatch") and table_opt in ("dense", "sparse")
         assert item_shard in ("replicate", "rows")
         self.lib = L.lib()
@@ -196,6 +200,13 @@ class HipBPRTrainer:
             self._mt_p = PA(*[x[0].data_ptr() for x in ts]); self._mt_g = PA(*[x[1].data_ptr() for x in ts])
             self._mt_m = PA(*[x[2].data_ptr() for x in ts]); self._mt_v = PA(*[x[3].data_ptr() for x in ts])
             self._mt_n = NA(*[x[0].numel() for x in ts])
+
+        can_persist = (loss_mode == "sampled" and table_opt == "dense" and not self.dist
+                       and bool(self.lib.rihip_bpr_step_persistent_supported(self.B, d, H)))
+        if persistent and not can_persist:
+            raise ValueError("persistent=True needs loss_mode='sampled', table_opt='dense', one GPU and B <= 2048")
+        self.persistent = can_persist if persistent is None else bool(persistent)
+        self._pargs = None
 
         # ---- per-step buffers
         f32 = dict(dtype=torch.float32, device=self.dev)
@@ -359,7 +370,47 @@ class HipBPRTrainer:
         self._graph.replay()
         return self.loss
 
+    def _step_persistent(self, user_ids: torch.Tensor, item_ids: torch.Tensor, item_genres: torch.Tensor) -> torch.Tensor:
+        """the whole step in one launch (rihip_bpr_step_persistent); the argument block is built once, only the three
+        input pointers change from step to step"""
+        a = self._pargs
+        if a is None:
+            ukeys, ikeys = _MLP_KEYS[:4], _MLP_KEYS[4:]
+            a = self._pargs = L.StepArgs()
+            s0 = (self.seed * 1000003 + self.rank * 7919) & ((1 << 62) - 1)
+            for io, (tab, keys, out, hid, den, gout, dX, bws, seed, n) in zip((a.user, a.item), (
+                    (self.utab, ukeys, self.U, self.hidU, self.denU, self.dU, self.dXu, self.bws_u, s0, self.B),
+                    (self.itab, ikeys, self.I, self.hidI, self.denI, self.dI, self.dXi, self.bws_i, s0 + 1, self.nI))):
+                io.table, io.n_rows, io.B = tab.data_ptr(), tab.shape[0], n
+                io.W1, io.b1, io.W2, io.b2 = (self.pv[k].data_ptr() for k in keys)
+                io.seed, io.row0 = seed, 0
+                io.out, io.hid, io.denom, io.fwd_workspace = out.data_ptr(), hid.data_ptr(), den.data_ptr(), None
+                io.grad_out, io.dX, io.bwd_workspace = gout.data_ptr(), dX.data_ptr(), bws.data_ptr()
+            g = self.gv
+            (a.dW1_u, a.db1_u, a.dW2_u, a.db2_u) = (g[k].data_ptr() for k in ukeys)
+            (a.dW1_i, a.db1_i, a.dW2_i, a.db2_i) = (g[k].data_ptr() for k in ikeys)
+            a.flat_p, a.flat_g, a.flat_m, a.flat_v = (x.data_ptr() for x in (self.flat_p, self.flat_g, self.flat_m, self.flat_v))
+            a.n_flat = self.flat_p.numel()
+            a.utab_g, a.utab_m, a.utab_v = self.uopt.grad.data_ptr(), self.uopt.m.data_ptr(), self.uopt.v.data_ptr()
+            a.itab_g, a.itab_m, a.itab_v = self.iopt.grad.data_ptr(), self.iopt.m.data_ptr(), self.iopt.v.data_ptr()
+            a.d, a.hidden = self.d, self.H
+            a.beta1, a.beta2, a.eps, a.weight_decay, a.max_norm = self.b1, self.b2, self.eps, self.wd, self.max_norm
+            a.lr_dev, a.step_dev, a.hyper_dev = self.lr_dev.data_ptr(), self.step_dev.data_ptr(), self.hyper_dev.data_ptr()
+            a.coef, a.gnorm, a.loss, a.err_flag = (x.data_ptr() for x in (self.coef, self.gnorm, self.loss, self.err))
+            nsd = int(self.lib.rihip_bpr_step_scratch_doubles(self.B))
+            self._pscratch = torch.zeros((nsd,), dtype=torch.float64, device=self.dev)
+            self._pbar = torch.zeros((4,), dtype=torch.int32, device=self.dev)
+            a.scratch_doubles, a.n_scratch_doubles, a.barrier = self._pscratch.data_ptr(), nsd, self._pbar.data_ptr()
+        a.user.ids, a.item.ids, a.item.genres = user_ids.data_ptr(), item_ids.data_ptr(), item_genres.data_ptr()
+        a.user.genres = None
+        a.training = 1 if (self.model.training and self.p_drop > 0) else 0
+        a.dropout_p = self.p_drop
+        L.check(self.lib.rihip_bpr_step_persistent(C.byref(a), L.stream_ptr()), "bpr_step_persistent")
+        return self.loss
+
     def _step_impl(self, user_ids: torch.Tensor, item_ids: torch.Tensor, item_genres: torch.Tensor) -> torch.Tensor:
+        if self.persistent:
+            return self._step_persistent(user_ids, item_ids, item_genres)
         lib, B, d = self.lib, self.B, self.d
         self._st = st = L.stream_ptr()
         t, lr = 0, 0.0   # the device clock (hyper_dev) overrides the host-side step / lr arguments below

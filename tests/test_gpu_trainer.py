@@ -27,16 +27,21 @@ def _params(sd, tower):
                          sd[f"{tower}.mlp.3.weight"], sd[f"{tower}.mlp.3.bias"])
 
 
+@pytest.mark.parametrize("persistent", [False, True])
 @pytest.mark.parametrize("use_graph", [False, True])
-def test_g4_train50_golden_fused_dense(golden_dir, use_graph):
+def test_g4_train50_golden_fused_dense(golden_dir, use_graph, persistent):
     """use_graph=True: the step is captured into a hipGraph on the second call and replayed 48 times; the device-side
-    Adam clock and the lr scalar must keep the run on the reference's trajectory (incl. the mid-run lr change)."""
+    Adam clock and the lr scalar must keep the run on the reference's trajectory (incl. the mid-run lr change).
+    persistent=True: the whole step is ONE launch (csrc/step_persistent.hip, three grid barriers); False: the seven
+    dependent launches."""
     from recommendit_amd.trainer import HipBPRTrainer, cosine_lr
     g = np.load(golden_dir / "g4_train50.npz")
     nu, ni, d, H, seed, B = (int(x) for x in g["cfg"])
     m, sd = _model(nu, ni, d, H, seed)
     m.train()
-    tr = HipBPRTrainer(m, B, lr=1e-2, weight_decay=1e-5, loss_mode="sampled", table_opt="dense", use_graph=use_graph)
+    tr = HipBPRTrainer(m, B, lr=1e-2, weight_decay=1e-5, loss_mode="sampled", table_opt="dense", use_graph=use_graph,
+                       persistent=persistent)
+    assert tr.persistent == persistent
     epoch = 0
     for step in range(50):
         u, p, gp, n, gn = fx.make_batch(nu, ni, B, seed=4000 + step, boundary=False)
@@ -45,8 +50,40 @@ def test_g4_train50_golden_fused_dense(golden_dir, use_graph):
         if step == 24:
             epoch += 1
     assert (tr._graph is not None) == use_graph
+    tr.check_errors()
     for k, prm in m.named_parameters():   # module parameters are views of the trainer's buffers
         np.testing.assert_allclose(prm.detach().cpu().numpy(), g[f"final_{k}"], atol=2e-4, rtol=0, err_msg=k)
+
+
+@pytest.mark.parametrize("cfg", [(6040, 3952, 64, 128, 256), (300, 500, 64, 128, 1024), (90, 70, 48, 96, 33),
+                                 (200, 50, 128, 128, 2048), (50, 40, 32, 64, 1)])
+def test_persistent_step_equals_the_multi_launch_step(cfg):
+    """one persistent launch vs the seven dependent launches on the same batches, dropout ON (same counter-based masks):
+    losses, clip coefficient and every parameter after 6 steps agree to float-summation-order level; duplicates in
+    the batch (few items, many samples) exercise the in-order scatter"""
+    from recommendit_amd.trainer import HipBPRTrainer
+    nu, ni, d, H, B = cfg
+    outs = []
+    for persistent in (False, True):
+        m, sd = _model(nu, ni, d, H, seed=3, dropout=0.1)
+        m.train()
+        tr = HipBPRTrainer(m, B, lr=5e-3, weight_decay=1e-5, loss_mode="sampled", table_opt="dense", seed=5,
+                           persistent=persistent)
+        losses, norms = [], []
+        for step in range(6):
+            u, p, gp, n, gn = fx.make_batch(nu, ni, B, seed=step * 7 + 1, boundary=False)
+            losses.append(tr.step(t(u), t(np.concatenate([p, n])), t(np.concatenate([gp, gn]))).item())
+            norms.append(tr.gnorm.item())
+        tr.check_errors()
+        assert int(tr.step_dev.item()) == 7
+        assert float(tr.uopt.grad.abs().max()) == 0.0 and float(tr.iopt.grad.abs().max()) == 0.0   # left zeroed
+        outs.append((losses, norms, {k: v.detach().cpu().numpy().copy() for k, v in m.named_parameters()}))
+    np.testing.assert_allclose(outs[1][0], outs[0][0], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=2e-5)
+    for k in outs[0][2]:
+        a, b = outs[0][2][k], outs[1][2][k]
+        np.testing.assert_allclose(b, a, atol=2e-3, rtol=0, err_msg=k)      # Adam's eps region: see test_gpu_generic_shapes
+        assert np.sum(np.abs(a - b) > 3e-5) <= max(1, int(1e-3 * a.size)), k
 
 
 def test_graph_replay_equals_eager_sparse_inbatch():
