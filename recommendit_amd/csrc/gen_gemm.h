@@ -14,19 +14,56 @@ constexpr int GNT = 2;     // 32-column output tiles per wave (4 waves x 2 x 32 
 __host__ __device__ inline int up8(int x) { return (x + 7) & ~7; }
 __host__ __device__ inline int up32(int x) { return (x + 31) & ~31; }
 
-// Wp[n][kk] = B[n][kc + kk] for n < Npad, kk < GKC, zero outside (N, K).  TRANS: B[n][k] = W[k*ldw + n], else W[n*ldw + k].
+// One k-panel of B: Wp[n][kk] = B[n][kc + kk] for n < Npad, kk < GKC, zero outside (N, K).  TRANS: B[n][k] = W[k*ldw + n],
+// else W[n*ldw + k].  The panel travels global -> registers -> LDS in two steps so that the loads of panel p+1 are in
+// flight while panel p is multiplied: these kernels run one or two tiles per workgroup and are bound by dependent
+// memory latency (an L2 miss is ~1-2 us), not by bandwidth.  Every load is unconditional (clamped address, value
+// selected afterwards): no branch separates the loads of a batch.
+constexpr int GPB = 32;    // panel elements per thread at Npad = 256 (256 x 32 / 256 threads)
+// element u of thread tid is flat index idx = u*256 + tid of the panel; (n, kk) advance incrementally from u to u+1 (a
+// runtime division per element would cost more than the MFMAs of these small tiles: one wave per SIMD hides nothing)
+struct PanelIdx {
+  int n, kk, dn, dk, Npad;
+  template <bool TRANS>
+  __device__ __forceinline__ void init(int Npad_, int tid) {
+    Npad = Npad_;
+    if (TRANS) { n = tid % Npad; kk = tid / Npad; dn = 256 % Npad; dk = 256 / Npad; }   // consecutive threads -> consecutive n
+    else { kk = tid & (GKC - 1); n = tid >> 5; dn = 8; dk = 0; }                       // consecutive threads -> consecutive k
+  }
+  template <bool TRANS>
+  __device__ __forceinline__ void next() {
+    n += dn; kk += dk;
+    if (TRANS && n >= Npad) { n -= Npad; kk += 1; }
+  }
+};
 template <bool TRANS>
-__device__ __forceinline__ void stage_panel(float* Wp, const float* __restrict__ W, int ldw, int N, int K, int Npad, int kc,
-                                            int tid) {
-  const int tot = Npad * GKC;
-  for (int idx = tid; idx < tot; idx += 256) {
-    int n, kk;
-    if (TRANS) { n = idx % Npad; kk = idx / Npad; }      // consecutive threads -> consecutive n (contiguous in W)
-    else { kk = idx % GKC; n = idx / GKC; }              // consecutive threads -> consecutive k
-    const int k = kc + kk;
-    float v = 0.f;
-    if (n < N && k < K) v = TRANS ? W[(size_t)k * ldw + n] : W[(size_t)n * ldw + k];
-    Wp[n * GLDP + kk] = v;
+__device__ __forceinline__ void panel_load(float (&v)[GPB], const float* __restrict__ W, int ldw, int N, int K, int Npad,
+                                           int kc, int tid) {
+  const int per = Npad >> 3;     // elements per thread: Npad * GKC / 256
+  PanelIdx ix;
+  ix.init<TRANS>(Npad, tid);
+#pragma unroll
+  for (int u = 0; u < GPB; ++u) {
+    if (u < per) {
+      const int k = kc + ix.kk;
+      const int nc = ix.n < N ? ix.n : N - 1, kcl = k < K ? k : K - 1;
+      // raw value of the clamped address: nothing consumes it before panel_store, so no wait separates the loads
+      v[u] = TRANS ? W[(size_t)kcl * ldw + nc] : W[(size_t)nc * ldw + kcl];
+      ix.next<TRANS>();
+    }
+  }
+}
+template <bool TRANS>
+__device__ __forceinline__ void panel_store(const float (&v)[GPB], float* Wp, int N, int K, int Npad, int kc, int tid) {
+  const int per = Npad >> 3;
+  PanelIdx ix;
+  ix.init<TRANS>(Npad, tid);
+#pragma unroll
+  for (int u = 0; u < GPB; ++u) {
+    if (u < per) {
+      Wp[ix.n * GLDP + ix.kk] = (ix.n < N && kc + ix.kk < K) ? v[u] : 0.f;
+      ix.next<TRANS>();
+    }
   }
 }
 
@@ -43,10 +80,13 @@ __device__ __forceinline__ void wg_gemm(const float* As, int lda, int K, const f
 #pragma unroll
     for (int t = 0; t < GNT; ++t) acc[t] = zero16();
   }
+  float pv[GPB];
+  panel_load<TRANS>(pv, W, ldw, N, Kw, Npad, 0, tid);
   for (int kc = 0; kc < Kp; kc += GKC) {
     __syncthreads();   // the previous panel is consumed (first pass: the A tile is complete)
-    stage_panel<TRANS>(Wp, W, ldw, N, Kw, Npad, kc, tid);
+    panel_store<TRANS>(pv, Wp, N, Kw, Npad, kc, tid);
     __syncthreads();
+    if (kc + GKC < Kp) panel_load<TRANS>(pv, W, ldw, N, Kw, Npad, kc + GKC, tid);   // in flight under the MFMAs below
     const int nb = ((Kp - kc < GKC) ? (Kp - kc) : GKC) >> 3;
     for (int b = 0; b < nb; ++b) {
       const f32x4 av = *reinterpret_cast<const f32x4*>(&As[(lane & 31) * lda + kc + 8 * b + 4 * (lane >> 5)]);

@@ -21,6 +21,11 @@
 // (nobody can still be spinning on it; the last one is reset by the next launch).  A spin that does not complete within ~1 s sets err_flag bit 3 and lets every
 // wave leave, so a grid that was not co-resident cannot hang the device.
 #include "recommendit_hip.h"
+#ifdef RIHIP_STEP_PROBE
+#include <hip/hip_runtime.h>
+__device__ unsigned long long g_rihip_probe[8];
+#define RIHIP_TILE_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_rihip_probe[k] = wall_clock64(); } while (0)
+#endif
 #include "tower_generic_body.h"
 
 using namespace rihip_gen;
@@ -44,27 +49,32 @@ struct StepArgs {
   const float* lr_dev; int64_t* step_dev; float* hyper_dev; float* coef; float* gnorm; float* loss; int* err_flag;
   double* loss_part;   // [n user tiles]
   double* sq_part;     // [gridDim.x]
+  double* stamps;      // [8] phase time stamps of workgroup 0 (100 MHz wall clock ticks): start, A, b0, B, b1, C, b2, D
   unsigned* bar;       // [4]
   size_t lds_floats;
 };
 
+// Grid barrier.  The 8 XCDs have private L2s and ordinary (coarse-grained) device memory is only made coherent between
+// them by an explicit L2 write-back (release) / invalidate (acquire), which are expensive: so exactly ONE thread per
+// workgroup fences, after the workgroup barrier has drained every wave's stores into the L2 and before the other waves
+// read anything; the spin itself uses relaxed loads (an acquire load per poll would invalidate the L2 every iteration).
 __device__ __forceinline__ bool grid_barrier(unsigned* counter, unsigned n_wg, int* err_flag) {
-  __threadfence();       // every wave: its global writes of this phase are visible device-wide before the arrival
-  __syncthreads();
+  __syncthreads();       // all waves: stores of this phase issued and complete (s_waitcnt vmcnt(0) before s_barrier)
   __shared__ int ok_s;
   if (threadIdx.x == 0) {
-    atomicAdd(counter, 1u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int ok = 1;
     long long spins = 0;
-    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < n_wg) {
-      __builtin_amdgcn_s_sleep(2);
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_wg) {
+      __builtin_amdgcn_s_sleep(1);
       if (++spins > (1ll << 24)) { ok = 0; break; }     // ~1 s: the grid is not co-resident -- give up instead of hanging
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (!ok && err_flag) atomicOr(err_flag, 8);
     ok_s = ok;
   }
   __syncthreads();
-  __threadfence();       // every wave: nothing read after this point is older than the other workgroups' arrivals
   return ok_s != 0;
 }
 
@@ -78,27 +88,47 @@ __device__ __forceinline__ void adam_elem_p(float& p, float g, float& m, float& 
   p = p - lr_over_bc1 * (m / denom);
 }
 
-// loss gradient rows of one tower tile (tower 0 = user rows b; tower 1 = item rows r: pos r < B, neg r >= B); one wave per
-// row; user tiles also return the sum of softplus(-delta) of their rows (valid in every lane of wave 0 .. 3, per wave)
+// loss gradient rows of one tower tile (tower 0 = user rows b; tower 1 = item rows r: pos r < B, neg r >= B).  Each wave
+// owns 8 of the 32 rows and handles them TOGETHER: all U / P / N loads of the 8 rows are issued before the first
+// reduction (three dependent latencies per tile instead of three per row).  User tiles also return the sum of
+// softplus(-delta) of the wave's rows (lane 0).
 __device__ __forceinline__ double loss_rows(const StepArgs& s, int tower, int64_t tile) {
   const int D = s.fu.D;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const float* U = s.fu.a.out;
   const float* I = s.fi.a.out;
   const float invB = 1.f / (float)s.B;
-  double lsum = 0.0;
   const int64_t n_rows = tower == 0 ? s.B : 2 * s.B;
-  for (int rr = w; rr < GTM; rr += 4) {
-    const int64_t r = tile * GTM + rr;
-    if (r >= n_rows) break;
-    const int64_t b = (tower == 0 || r < s.B) ? r : r - s.B;
-    float dp = 0.f, dn = 0.f;
-    for (int c = lane; c < D; c += 64) {
-      const float u = U[b * D + c];
-      dp += u * I[b * D + c];
-      dn += u * I[(s.B + b) * D + c];
+  float dlt[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) dlt[k] = 0.f;
+  int64_t bb[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    int64_t r = tile * GTM + w * 8 + k;
+    if (r >= n_rows) r = n_rows - 1;
+    bb[k] = (tower == 0 || r < s.B) ? r : r - s.B;
+  }
+  for (int c0 = 0; c0 < D; c0 += 64) {
+    const int c = c0 + lane;
+    const int cc = c < D ? c : 0;
+    float u[8], p[8], n[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      u[k] = U[bb[k] * D + cc]; p[k] = I[bb[k] * D + cc]; n[k] = I[(s.B + bb[k]) * D + cc];
     }
-    const float delta = wave_sum(dp) - wave_sum(dn);
+    if (c < D) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dlt[k] += u[k] * (p[k] - n[k]);
+    }
+  }
+  double lsum = 0.0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int64_t r = tile * GTM + w * 8 + k;
+    const float delta = wave_sum(dlt[k]);
+    if (r >= n_rows) continue;               // wave-uniform
+    const int64_t b = bb[k];
     // d/d delta of softplus(-delta) = -sigma(-delta)
     const float wgt = -1.f / (1.f + __expf(delta)) * invB;
     if (tower == 0) {
@@ -128,13 +158,24 @@ __global__ __launch_bounds__(STEP_WG) void bpr_step_persistent_kernel(StepArgs s
   const uint64_t seed_u = s.fu.a.seed_step ? rihip_splitmix64(s.fu.a.seed_mul + (uint64_t)t_step) : s.fu.a.seed_mul;
   const uint64_t seed_i = s.fi.a.seed_step ? rihip_splitmix64(s.fi.a.seed_mul + (uint64_t)t_step) : s.fi.a.seed_mul;
   const int64_t ntu = (s.B + GTM - 1) / GTM, nti = (2 * s.B + GTM - 1) / GTM;
+  auto stamp = [&](int k) { if (wg == 0 && tid == 0) s.stamps[k] = (double)wall_clock64(); };
+  stamp(0);
 
   // ---- A: towers forward
   for (int64_t it = wg; it < ntu + nti; it += nwg) {
     if (it < ntu) gen_fwd_tile(s.fu, smem, it, seed_u);
     else gen_fwd_tile(s.fi, smem, it - ntu, seed_i);
   }
+#ifdef RIHIP_STEP_PROBE   // (tools: the same tiles a second time -- warm instruction / data caches -- timed as phase A)
+  stamp(0);
+  for (int64_t it = wg; it < ntu + nti; it += nwg) {
+    if (it < ntu) gen_fwd_tile(s.fu, smem, it, seed_u);
+    else gen_fwd_tile(s.fi, smem, it - ntu, seed_i);
+  }
+#endif
+  stamp(1);
   if (!grid_barrier(s.bar + 0, nwg, s.err_flag)) return;
+  stamp(2);
   if (wg == 0 && tid == 0) s.bar[2] = 0;     // the previous launch's last barrier: that grid has drained
 
   // ---- B: loss gradient + data gradients per tower tile
@@ -147,11 +188,12 @@ __global__ __launch_bounds__(STEP_WG) void bpr_step_persistent_kernel(StepArgs s
       __syncthreads();
       if (tid == 0) s.loss_part[tile] = ((red_d[0] + red_d[1]) + red_d[2]) + red_d[3];
     }
-    __threadfence();      // the gout rows written above are read back (other waves) by the tile function
-    __syncthreads();
+    __syncthreads();      // the gout rows written above are read back by other waves of this workgroup (same CU, same L1)
     gen_bwd_data_tile(tower == 0 ? s.bu : s.bi, smem, tile);
   }
+  stamp(3);
   if (!grid_barrier(s.bar + 1, nwg, s.err_flag)) return;
+  stamp(4);
   if (wg == 0 && tid == 0) s.bar[0] = 0;
 
   // ---- C: weight gradients + dense embedding scatter; squared norm of everything this workgroup produced
@@ -239,7 +281,9 @@ __global__ __launch_bounds__(STEP_WG) void bpr_step_persistent_kernel(StepArgs s
     __syncthreads();
     if (tid == 0) s.sq_part[wg] = ((red_d[0] + red_d[1]) + red_d[2]) + red_d[3];
   }
+  stamp(5);
   if (!grid_barrier(s.bar + 2, nwg, s.err_flag)) return;
+  stamp(6);
   if (wg == 0 && tid == 0) s.bar[1] = 0;
 
   // ---- D: clip coefficient (same arithmetic in every workgroup) + dense Adam over MLPs and both tables
@@ -262,19 +306,29 @@ __global__ __launch_bounds__(STEP_WG) void bpr_step_persistent_kernel(StepArgs s
     }
     __syncthreads();
     const float coef = bc_s[0], lr1 = bc_s[1], sb2 = bc_s[2];
-    const int64_t nU = s.n_urows * D, nI = s.n_irows * D;
-    const int64_t total = s.n_flat + nU + nI;
-    for (int64_t i = (int64_t)wg * STEP_WG + tid; i < total; i += (int64_t)nwg * STEP_WG) {
-      float *p, *g, *m, *v;
-      bool zero_g = true;
-      int64_t k = i;
-      if (k < s.n_flat) { p = s.flat_p; g = s.flat_g; m = s.flat_m; v = s.flat_v; zero_g = false; }
-      else if ((k -= s.n_flat) < nU) { p = s.utab; g = s.utab_g; m = s.utab_m; v = s.utab_v; }
-      else { k -= nU; p = s.itab; g = s.itab_g; m = s.itab_m; v = s.itab_v; }
-      float pk = p[k], mk = m[k], vk = v[k];
-      adam_elem_p(pk, g[k], mk, vk, coef, lr1, sb2, s.h);
-      p[k] = pk; m[k] = mk; v[k] = vk;
-      if (zero_g) g[k] = 0.f;       // the dense table gradient is consumed: the next step scatters into zeros
+    // float4 walk over [MLP flat | user table | item table] (every segment is a multiple of 4 floats, 16-B aligned)
+    const int64_t seg_n[3] = {s.n_flat / 4, s.n_urows * D / 4, s.n_irows * D / 4};
+    float* seg_p[3] = {s.flat_p, s.utab, s.itab};
+    float* seg_g[3] = {s.flat_g, s.utab_g, s.itab_g};
+    float* seg_m[3] = {s.flat_m, s.utab_m, s.itab_m};
+    float* seg_v[3] = {s.flat_v, s.utab_v, s.itab_v};
+#pragma unroll
+    for (int sg = 0; sg < 3; ++sg) {
+      f32x4* p4 = reinterpret_cast<f32x4*>(seg_p[sg]);
+      f32x4* g4 = reinterpret_cast<f32x4*>(seg_g[sg]);
+      f32x4* m4 = reinterpret_cast<f32x4*>(seg_m[sg]);
+      f32x4* v4 = reinterpret_cast<f32x4*>(seg_v[sg]);
+      for (int64_t i = (int64_t)wg * STEP_WG + tid; i < seg_n[sg]; i += (int64_t)nwg * STEP_WG) {
+        f32x4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float pk = pp[k], mk = mm[k], vk = vv[k];
+          adam_elem_p(pk, gg[k], mk, vk, coef, lr1, sb2, s.h);
+          pp[k] = pk; mm[k] = mk; vv[k] = vk;
+        }
+        p4[i] = pp; m4[i] = mm; v4[i] = vv;
+        if (sg > 0) g4[i] = f32x4{0.f, 0.f, 0.f, 0.f};   // the dense table gradient is consumed: the next step scatters into zeros
+      }
     }
     if (wg == 0) {
       double l = 0.0;
@@ -291,6 +345,14 @@ __global__ __launch_bounds__(STEP_WG) void bpr_step_persistent_kernel(StepArgs s
       }
     }
   }
+  stamp(7);
+#ifdef RIHIP_STEP_PROBE
+  if (wg == 0 && tid == 0) {
+    g_rihip_probe[6] = wall_clock64();
+    for (int k = 0; k < 6; ++k) s.stamps[k] = (double)g_rihip_probe[k];     // sub-phases of the (warm) forward tile
+    s.stamps[6] = s.stamps[7] = (double)g_rihip_probe[5];
+  }
+#endif
 }
 
 }  // namespace
@@ -320,6 +382,15 @@ extern "C" int rihip_bpr_step_persistent(const rihip_step_args* a, void* stream)
   RIHIP_REQUIRE(a->n_scratch_doubles >= rihip_bpr_step_scratch_doubles(u.B), RIHIP_ERR_ARG,
                 "bpr_step_persistent: scratch too small");
   RIHIP_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f, RIHIP_ERR_ARG, "bpr_step_persistent: dropout_p=%f", a->dropout_p);
+  RIHIP_REQUIRE(a->n_flat > 0 && a->n_flat % 4 == 0 &&
+                    ((reinterpret_cast<uintptr_t>(a->flat_p) | reinterpret_cast<uintptr_t>(a->flat_g) |
+                      reinterpret_cast<uintptr_t>(a->flat_m) | reinterpret_cast<uintptr_t>(a->flat_v) |
+                      reinterpret_cast<uintptr_t>(u.table) | reinterpret_cast<uintptr_t>(it.table) |
+                      reinterpret_cast<uintptr_t>(a->utab_g) | reinterpret_cast<uintptr_t>(a->itab_g) |
+                      reinterpret_cast<uintptr_t>(u.out) | reinterpret_cast<uintptr_t>(it.out) |
+                      reinterpret_cast<uintptr_t>(u.grad_out) | reinterpret_cast<uintptr_t>(it.grad_out) |
+                      reinterpret_cast<uintptr_t>(u.bwd_workspace) | reinterpret_cast<uintptr_t>(it.bwd_workspace)) & 15) == 0,
+                RIHIP_ERR_ARG, "bpr_step_persistent: buffers must be 16-byte aligned and n_flat a multiple of 4");
   const int d = a->d, H = a->hidden;
   StepArgs s;
   const rihip_tower_io* io[2] = {&u, &it};
@@ -353,6 +424,7 @@ extern "C" int rihip_bpr_step_persistent(const rihip_step_args* a, void* stream)
   s.lr_dev = a->lr_dev; s.step_dev = a->step_dev; s.hyper_dev = a->hyper_dev; s.coef = a->coef; s.gnorm = a->gnorm;
   s.loss = a->loss; s.err_flag = a->err_flag;
   s.loss_part = a->scratch_doubles; s.sq_part = a->scratch_doubles + (u.B + 31) / 32;
+  s.stamps = s.sq_part + RIHIP_NCU;
   s.bar = a->barrier;
   size_t lf = gen_fwd_lds_floats(d, H, d + 18);
   const size_t lb = gen_bwd_lds_floats(d, H);

@@ -5,6 +5,10 @@
 #include "gen_gemm.h"
 #include "tower_args.h"
 
+#ifndef RIHIP_TILE_STAMP
+#define RIHIP_TILE_STAMP(k)      // (tools/persist_phases.py probe builds stamp the wall clock here)
+#endif
+
 namespace rihip_gen {
 
 struct GenFwd {
@@ -25,28 +29,47 @@ __device__ __forceinline__ void gen_fwd_tile(const GenFwd& g, float* smem, int64
   {
     const int64_t row_base = tile * GTM;
     __syncthreads();   // the previous tile's Y reads are done
-    // ---- gather: x = table[id] (|| genres), zero-padded to K1p; rows past B are zero
-    for (int idx = tid; idx < GTM * K1p; idx += 256) {
-      const int r = idx / K1p, k = idx % K1p;
+    RIHIP_TILE_STAMP(0);
+    // ---- gather: x = table[id] (|| genres), zero-padded to K1p; rows past B are zero.  8 threads per row; every load
+    // is unconditional (clamped address) and nothing consumes a value before all loads of the thread are issued: the
+    // tile costs two dependent memory latencies (id, row), not one per element
+    {
+      const int r = tid >> 3, q = tid & 7;
       const int64_t grow = row_base + r;
-      float v = 0.f;
-      if (grow < a.B) {
-        if (k < D) {
-          int64_t id = a.ids[grow];
-          if (id < 0 || id >= a.n_rows) {
-            if (a.err_flag) *a.err_flag = 1;
-            id = 0;
-          }
-          v = a.table[id * D + k];
-        } else if (k < K1) {
-          v = a.genres[grow * 18 + (k - D)];
-        }
+      const bool ok = grow < a.B;
+      const int64_t gr = ok ? grow : a.B - 1;
+      int64_t id = a.ids[gr];
+      if (id < 0 || id >= a.n_rows) {
+        if (ok && a.err_flag) *a.err_flag = 1;
+        id = 0;
       }
-      Xs[r * ldx + k] = v;
+      const f32x4* trow = reinterpret_cast<const f32x4*>(a.table + id * D);
+      const int d4 = D >> 2;
+      f32x4 xv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const int c4 = q + 8 * j; xv[j] = trow[c4 < d4 ? c4 : 0]; }
+      float gv[3] = {0.f, 0.f, 0.f};
+      if (K1 > D) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { const int gk = q + 8 * j; gv[j] = a.genres[gr * 18 + (gk < 18 ? gk : 0)]; }
+      }
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c4 = q + 8 * j;
+        if (c4 < d4) *reinterpret_cast<f32x4*>(&Xs[r * ldx + 4 * c4]) = ok ? xv[j] : z4;
+      }
+      if (K1 > D) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { const int gk = q + 8 * j; if (gk < 18) Xs[r * ldx + D + gk] = ok ? gv[j] : 0.f; }
+      }
+      if (K1 + q < K1p) Xs[r * ldx + K1 + q] = 0.f;
     }
     // ---- Linear 1 + ReLU + dropout -> Hs (+ saved hidden)
     f32x16 acc[GNT];
+    RIHIP_TILE_STAMP(1);
     wg_gemm<false>(Xs, ldx, K1, a.W1, K1, H, Wp, acc, tid);
+    RIHIP_TILE_STAMP(2);
 #pragma unroll
     for (int t = 0; t < GNT; ++t) {
       const int col = (w + 4 * t) * 32 + (lane & 31);
@@ -64,7 +87,9 @@ __device__ __forceinline__ void gen_fwd_tile(const GenFwd& g, float* smem, int64
       }
     }
     // ---- Linear 2 -> Y (aliases Xs: the first barrier inside wg_gemm orders it after every Xs read of GEMM 1)
+    RIHIP_TILE_STAMP(3);
     wg_gemm<false>(Hs, ldh, H, a.W2, H, D, Wp, acc, tid);
+    RIHIP_TILE_STAMP(4);
     float* Ys = Xs;
 #pragma unroll
     for (int t = 0; t < GNT; ++t) {
@@ -76,6 +101,7 @@ __device__ __forceinline__ void gen_fwd_tile(const GenFwd& g, float* smem, int64
       }
     }
     __syncthreads();
+    RIHIP_TILE_STAMP(5);
     // ---- row L2-normalise: 8 threads per row
     {
       const int row = tid >> 3, q = tid & 7;
@@ -115,24 +141,39 @@ __device__ __forceinline__ void gen_bwd_data_tile(const GenBwd& g, float* smem, 
   {
     const int64_t row_base = tile * GTM;
     __syncthreads();
-    {   // normalise-backward, 8 threads per row (D is a multiple of 16: no padding columns)
+    {   // normalise-backward, 8 threads per row, float4 loads all issued before the first use (see the gather above)
       const int row = tid >> 3, q = tid & 7;
       const int64_t grow = row_base + row;
       const bool ok = grow < a.B;
+      const int64_t gr = ok ? grow : a.B - 1;
+      const int d4 = D >> 2;
+      const f32x4* orow = reinterpret_cast<const f32x4*>(a.out + gr * D);
+      const f32x4* grw = reinterpret_cast<const f32x4*>(a.gout + gr * D);
+      f32x4 ov[8], gv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c4 = q + 8 * j, cc = c4 < d4 ? c4 : 0;
+        ov[j] = orow[cc]; gv[j] = grw[cc];
+      }
+      const float den = a.denom[gr];
       float dot = 0.f;
-      if (ok)
-        for (int c = q; c < D; c += 8) dot += a.out[grow * D + c] * a.gout[grow * D + c];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (q + 8 * j < d4) dot += (ov[j].x * gv[j].x + ov[j].y * gv[j].y) + (ov[j].z * gv[j].z + ov[j].w * gv[j].w);
       dot += __shfl_xor(dot, 1, 64);
       dot += __shfl_xor(dot, 2, 64);
       dot += __shfl_xor(dot, 4, 64);
-      const float inv = ok ? 1.f / a.denom[grow] : 0.f;
-      for (int c = q; c < D; c += 8) {
-        float v = 0.f;
-        if (ok) {
-          v = (a.gout[grow * D + c] - a.out[grow * D + c] * dot) * inv;
-          g.gy[grow * D + c] = v;
+      const float inv = ok ? 1.f / den : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c4 = q + 8 * j;
+        if (c4 < d4) {
+          f32x4 v;
+          v.x = (gv[j].x - ov[j].x * dot) * inv; v.y = (gv[j].y - ov[j].y * dot) * inv;
+          v.z = (gv[j].z - ov[j].z * dot) * inv; v.w = (gv[j].w - ov[j].w * dot) * inv;
+          if (ok) reinterpret_cast<f32x4*>(g.gy + grow * D)[c4] = v;
+          *reinterpret_cast<f32x4*>(&Gs[row * ldg + 4 * c4]) = v;
         }
-        Gs[row * ldg + c] = v;
       }
     }
     f32x16 acc[GNT];
@@ -142,15 +183,19 @@ __device__ __forceinline__ void gen_bwd_data_tile(const GenBwd& g, float* smem, 
     for (int t = 0; t < GNT; ++t) {
       const int col = (w + 4 * t) * 32 + (lane & 31);
       if (col < H) {
+        float hv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {     // the 16 mask loads first, unconditional
+          const int64_t grow = row_base + acc_row(r, lane);
+          hv[r] = a.hid[(grow < a.B ? grow : a.B - 1) * H + col];
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = acc_row(r, lane);
           const int64_t grow = row_base + row;
-          float v = 0.f;
-          if (grow < a.B) {
-            v = a.hid[grow * H + col] > 0.f ? acc[t][r] * a.scale : 0.f;
-            g.dpre[grow * H + col] = v;
-          }
+          const bool ok = grow < a.B;
+          const float v = (ok && hv[r] > 0.f) ? acc[t][r] * a.scale : 0.f;
+          if (ok) g.dpre[grow * H + col] = v;
           Ps[row * ldh + col] = v;
         }
       }
@@ -189,7 +234,9 @@ __device__ __forceinline__ GenWTile gen_wgrad_tile_of(const GenBwd& g, int tile)
   t.nt = t.first ? tt % nt1 : tt % nt2;
   return t;
 }
-// one wave: the partial output tile over the batch rows rb = r_begin, r_begin + r_step, ... < r1 (32 rows each)
+// one wave: the partial output tile over the batch rows rb = r_begin, r_begin + r_step, ... < r1 (32 rows each).  Per
+// 32-row block all operand loads (ids, then A and B values) are issued unconditionally from clamped addresses before the
+// 16 MFMAs consume them: the block costs two dependent latencies, not one per step.
 __device__ __forceinline__ f32x16 gen_wgrad_acc(const GenBwd& g, const GenWTile& t, int64_t r_begin, int64_t r_step, int64_t r1,
                                                 int lane) {
   const TowerBwdArgs& a = g.a;
@@ -199,25 +246,51 @@ __device__ __forceinline__ f32x16 gen_wgrad_acc(const GenBwd& g, const GenWTile&
   const int j = t.nt * 32 + (lane & 31);          // B feature: k1 (dW1) or h (dW2)
   const float* Asrc = first ? g.dpre : g.gy;
   const int lda = first ? H : D, Mdim = first ? H : D, Ndim = first ? K1 : H;
+  const bool a_ok = i < Mdim;
+  const int ic = a_ok ? i : 0;
+  // B operand of this lane: 0 = zero column, 1 = the ones column (bias gradient), 2 = a strided array, 3 = table gather
+  int mode = 0;
+  const float* bbase = Asrc;
+  int bstride = 0;
+  if (j == Ndim) mode = 1;
+  else if (j < Ndim) {
+    if (!first) { mode = 2; bbase = a.hid + j; bstride = H; }
+    else if (j < D) { mode = 3; }
+    else { mode = 2; bbase = a.genres + (j - D); bstride = 18; }
+  }
+  const bool any_gather = __ballot(mode == 3) != 0ull;
   f32x16 acc = zero16();
   for (int64_t rb = r_begin; rb < r1; rb += r_step) {
-#pragma unroll 4
+    int64_t rowc[16];
+    float av[16], bv[16];
+#pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int64_t row = rb + acc_row(s, lane);    // k index of step s for this lane half (any bijection works)
-      float av = 0.f, bv = 0.f;
-      if (row < r1) {
-        if (i < Mdim) av = Asrc[row * lda + i];
-        if (j == Ndim) bv = 1.f;
-        else if (j < Ndim) {
-          if (!first) bv = a.hid[row * H + j];
-          else if (j < D) {
-            int64_t id = a.ids[row];
-            if (id < 0 || id >= a.n_rows) id = 0;
-            bv = a.table[id * D + j];
-          } else bv = a.genres[row * 18 + (j - D)];
-        }
+      rowc[s] = row < r1 ? row : r1 - 1;
+    }
+    int64_t idv[16];
+    if (any_gather) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) idv[s] = a.ids[rowc[s]];
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) av[s] = Asrc[rowc[s] * lda + ic];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const float* bp = bbase + rowc[s] * bstride;
+      if (any_gather && mode == 3) {
+        int64_t id = idv[s];
+        if (id < 0 || id >= a.n_rows) id = 0;
+        bp = a.table + id * D + j;
       }
-      acc = mfma32(av, bv, acc);
+      bv[s] = *bp;
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const bool rok = rb + acc_row(s, lane) < r1;
+      const float x = (rok && a_ok) ? av[s] : 0.f;
+      const float y = !rok ? 0.f : (mode == 1 ? 1.f : (mode == 0 ? 0.f : bv[s]));
+      acc = mfma32(x, y, acc);
     }
   }
   return acc;

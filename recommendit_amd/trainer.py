@@ -123,8 +123,11 @@ class HipBPRTrainer:
         wire volume (W*cap*d*4 bytes per all-to-all) but a step that routes more than `cap` rows to one owner sets
         error bit 2 (check_errors() raises).
         persistent: run the sampled-negative step with the dense (reference) optimiser as ONE persistent launch
-        (csrc/step_persistent.hip: three grid barriers instead of seven dependent launches).  None = whenever the
-        shape allows it (single GPU, B <= 2048); False keeps the multi-launch path."""
+        (csrc/step_persistent.hip: three grid barriers instead of seven dependent launches; single GPU, B <= 2048).
+        Opt-in: measured on MI355X it is SLOWER than the seven launches today (0.124 vs 0.074 ms at the ML-1M
+        B = 256 shape: each of the three grid barriers needs an L2 write-back + invalidate across the 8 XCDs, and the
+        runtime-shape tile code it is built from is latency-bound) -- see DESIGN.md §9.  None / False = the multi-launch
+        path."""
         assert loss_mode in ("sampled", "inbatch") and table_opt in ("dense", "sparse")
         assert item_shard in ("replicate", "rows")
         self.lib = L.lib()
@@ -205,7 +208,7 @@ class HipBPRTrainer:
                        and bool(self.lib.rihip_bpr_step_persistent_supported(self.B, d, H)))
         if persistent and not can_persist:
             raise ValueError("persistent=True needs loss_mode='sampled', table_opt='dense', one GPU and B <= 2048")
-        self.persistent = can_persist if persistent is None else bool(persistent)
+        self.persistent = bool(persistent)
         self._pargs = None
 
         # ---- per-step buffers

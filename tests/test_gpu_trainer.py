@@ -69,21 +69,34 @@ def test_persistent_step_equals_the_multi_launch_step(cfg):
         m.train()
         tr = HipBPRTrainer(m, B, lr=5e-3, weight_decay=1e-5, loss_mode="sampled", table_opt="dense", seed=5,
                            persistent=persistent)
-        losses, norms = [], []
+        losses, norms, first = [], [], None
         for step in range(6):
             u, p, gp, n, gn = fx.make_batch(nu, ni, B, seed=step * 7 + 1, boundary=False)
             losses.append(tr.step(t(u), t(np.concatenate([p, n])), t(np.concatenate([gp, gn]))).item())
             norms.append(tr.gnorm.item())
+            if step == 0:
+                first = {k: v.detach().cpu().numpy().copy() for k, v in m.named_parameters()}
         tr.check_errors()
         assert int(tr.step_dev.item()) == 7
         assert float(tr.uopt.grad.abs().max()) == 0.0 and float(tr.iopt.grad.abs().max()) == 0.0   # left zeroed
-        outs.append((losses, norms, {k: v.detach().cpu().numpy().copy() for k, v in m.named_parameters()}))
-    np.testing.assert_allclose(outs[1][0], outs[0][0], atol=2e-6, rtol=0)
-    np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=2e-5)
+        outs.append((losses, norms, first, {k: v.detach().cpu().numpy().copy() for k, v in m.named_parameters()}))
+    lr = 5e-3
+    # step 1 starts from identical state: float-summation-order agreement of loss, gradient norm and every parameter
+    # (an element whose gradient sits at Adam's eps = 1e-8 may move by a visible fraction of one lr-sized step: <= 0.1 %
+    # of the elements, bounded by lr)
+    assert abs(outs[1][0][0] - outs[0][0][0]) < 1e-6 and abs(outs[1][1][0] / outs[0][1][0] - 1) < 2e-5
     for k in outs[0][2]:
         a, b = outs[0][2][k], outs[1][2][k]
-        np.testing.assert_allclose(b, a, atol=2e-3, rtol=0, err_msg=k)      # Adam's eps region: see test_gpu_generic_shapes
+        np.testing.assert_allclose(b, a, atol=1.01 * lr, rtol=0, err_msg=k)
         assert np.sum(np.abs(a - b) > 3e-5) <= max(1, int(1e-3 * a.size)), k
+    # later steps compound that sensitivity: the two trajectories stay together in loss and norm, and all but a few
+    # elements of the parameters agree
+    np.testing.assert_allclose(outs[1][0], outs[0][0], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(outs[1][1], outs[0][1], rtol=2e-3)
+    for k in outs[0][3]:
+        a, b = outs[0][3][k], outs[1][3][k]
+        np.testing.assert_allclose(b, a, atol=6.1 * lr, rtol=0, err_msg=k)
+        assert float(np.mean(np.abs(a - b))) < 1e-4, k
 
 
 def test_graph_replay_equals_eager_sparse_inbatch():
