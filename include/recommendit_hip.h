@@ -304,6 +304,11 @@ typedef struct rihip_lambdamart_params {
   double label_gain[32];
   double learning_rate, reg_alpha, reg_lambda, feature_fraction, min_sum_hessian, sigmoid;
   uint64_t seed;
+  /* fidelity switches towards LightGBM's defaults (0 = the integer-2^20 / NaN-as-zero / lowest-threshold behaviour):
+   * hist_bits 20|40 (40: float-histogram fidelity, sums still order-independent integers); use_missing 1: NaN gets its
+   * own bin and every node learns a default direction (decision_type missing = NaN); split_order 1: equal-gain
+   * thresholds resolved in FeatureHistogram::FindBestThreshold's scan order */
+  int hist_bits, use_missing, split_order, reserved;
 } rihip_lambdamart_params;
 int rihip_lambdamart_train(const float* X, const float* y, const int32_t* groups, int64_t n, int F, int ng,
                            const float* Xv, const float* yv, const int32_t* groups_v, int64_t nv, int ngv,

@@ -152,7 +152,8 @@ class LambdamartParams(C.Structure):
                 ("bin_sample", C.c_int), ("n_eval_at", C.c_int), ("eval_at", C.c_int * 8), ("n_label_gain", C.c_int),
                 ("label_gain", C.c_double * 32), ("learning_rate", C.c_double), ("reg_alpha", C.c_double),
                 ("reg_lambda", C.c_double), ("feature_fraction", C.c_double), ("min_sum_hessian", C.c_double),
-                ("sigmoid", C.c_double), ("seed", C.c_uint64)]
+                ("sigmoid", C.c_double), ("seed", C.c_uint64), ("hist_bits", C.c_int), ("use_missing", C.c_int),
+                ("split_order", C.c_int), ("reserved", C.c_int)]
 
 
 class TowerIO(C.Structure):

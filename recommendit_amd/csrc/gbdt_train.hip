@@ -7,6 +7,16 @@
 // oracle/lambdamart_np.py (tests/test_gpu_lambdamart.py).  What makes "bit for bit" possible: gradients and hessians
 // are quantised to integers (2^20 levels of the largest magnitude) before they enter the histograms, so every
 // histogram entry is an integer sum, independent of the order of the atomics; gains are then evaluated in double.
+// Fidelity switches towards LightGBM's defaults (rihip_lambdamart_params, all off by default = the round-2 behaviour):
+//   hist_bits = 40   float-histogram fidelity: gradients enter at 2^-40 of the round's maximum (LightGBM accumulates float
+//                    gradients in double; 2^-40 is 65 536x finer than the float32 rounding of a gradient) and the sums
+//                    are still exact integers, i.e. independent of summation order (an f64 accumulation is not);
+//   use_missing = 1  NaN is a value of its own: a feature with NaN in the bin sample gets a last "missing" bin, every
+//                    threshold is tried with the missing rows on either side, the node stores the better default
+//                    direction (decision_type missing=NaN, default_left); 0: NaN is read as 0.0;
+//   split_order = 1  ties between equal-gain thresholds of a feature are resolved as FeatureHistogram::
+//                    FindBestThreshold does (right-to-left scan, strict '>': the HIGHEST threshold; then the
+//                    left-to-right scan with the missing rows on the right); 0: the lowest threshold.
 //
 //   binning        <= 255 bins per feature, upper bounds from a strided sample of <= 200 000 rows (host), rows binned
 //                  on the device (one byte per value: 145 MB for ML-1M's 2.9 M x 50 ranking rows)
@@ -26,6 +36,7 @@
 #include <string.h>
 #include <algorithm>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include <rocprim/rocprim.hpp>
@@ -37,13 +48,13 @@ namespace {
 
 constexpr int NBIN = 256;
 constexpr int HCH = 1024;        // rows per histogram workgroup: 1024 x 2^20 < 2^31 keeps int32 sums exact
-constexpr int FCH = 32;          // features per histogram pass (32 x 256 x 3 x 4 B = 96 KB of LDS)
+constexpr int FCH = 32;          // features per histogram pass (32 x 256 x 3 x 4 B = 96 KB of LDS; 16 with 8-byte cells)
 constexpr int MAX_GROUP = 16384; // documents per query (sorted scores + labels of a query live in LDS)
 constexpr int MAX_T = 32;        // truncation level supported by the per-thread pair accumulators
 constexpr double QLEVELS = 1048576.0;
 constexpr double K_EPS = 1e-15;
 
-struct SplitInfo { double gain; int feature, bin; long long glq, hlq, cl; long long gq, hq, c; };
+struct SplitInfo { double gain; int feature, bin; long long glq, hlq, cl; long long gq, hq, c; int default_left, pad; };
 
 __device__ __forceinline__ uint64_t d2ord_desc(double v) {  // ascending radix order == descending score
   uint64_t u = (uint64_t)__double_as_longlong(v);
@@ -51,15 +62,20 @@ __device__ __forceinline__ uint64_t d2ord_desc(double v) {  // ascending radix o
   return ~u;
 }
 
+// nanbin[f] >= 0: the feature has a "missing" bin (the last one) and NaN goes there; else NaN is read as 0.0
 __global__ void bin_rows_kernel(const float* __restrict__ X, int64_t n, int F, const double* __restrict__ ub,
-                                const int* __restrict__ nb, uint8_t* Xb) {
+                                const int* __restrict__ nb, const int* __restrict__ nanbin, uint8_t* Xb) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * F) return;
   const int f = (int)(i % F);
   double x = (double)X[i];
-  if (x != x) x = 0.0;
+  const int nbn = nanbin[f];
+  if (x != x) {
+    if (nbn >= 0) { Xb[i] = (uint8_t)nbn; return; }
+    x = 0.0;
+  }
   const double* u = ub + (size_t)f * NBIN;
-  int lo = 0, hi = nb[f] - 1;             // first bin with x <= upper bound (the last bound is +inf)
+  int lo = 0, hi = (nbn >= 0 ? nbn : nb[f]) - 1;   // first real bin with x <= upper bound (the last real bound is +inf)
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
     if (x <= u[mid]) hi = mid; else lo = mid + 1;
@@ -182,17 +198,22 @@ __global__ void unsort_absmax_kernel(const double* __restrict__ ls, const double
     atomicMax(&mx[1], (unsigned long long)__double_as_longlong(h));
   }
 }
+template <typename T>
 __global__ void quantize_kernel(const double* __restrict__ lam, const double* __restrict__ hes, int64_t n, double sg, double sh,
-                                int* gq, int* hq) {
+                                T* gq, T* hq) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { gq[i] = (int)llrint(lam[i] * sg); hq[i] = (int)llrint(hes[i] * sh); }
+  if (i < n) { gq[i] = (T)llrint(lam[i] * sg); hq[i] = (T)llrint(hes[i] * sh); }
 }
 
-// partial histograms of rows[b0 .. b0+len) over features [f0, f0+nf): int32 in LDS, added into the int64 histogram
+// partial histograms of rows[b0 .. b0+len) over features [f0, f0+nf): cells of type T in LDS (int32 for 2^20 levels: 1024
+// rows x 2^20 < 2^31; int64 for 2^40 levels), added into the int64 histogram
+template <typename T>
 __global__ __launch_bounds__(256) void hist_kernel(const uint8_t* __restrict__ Xb, int F, const int* __restrict__ rows,
-                                                   int64_t b0, int64_t len, const int* __restrict__ gq,
-                                                   const int* __restrict__ hq, int f0, int nf, long long* hist) {
-  extern __shared__ int hs[];   // [nf][NBIN][3]
+                                                   int64_t b0, int64_t len, const T* __restrict__ gq,
+                                                   const T* __restrict__ hq, int f0, int nf, long long* hist) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char hs_raw[];   // [nf][NBIN][3] of T
+  T* hs = reinterpret_cast<T*>(hs_raw);
+  using U = typename std::conditional<sizeof(T) == 8, unsigned long long, int>::type;
   const int tid = threadIdx.x;
   for (int i = tid; i < nf * NBIN * 3; i += 256) hs[i] = 0;
   __syncthreads();
@@ -200,16 +221,16 @@ __global__ __launch_bounds__(256) void hist_kernel(const uint8_t* __restrict__ X
   const int64_t c1 = (c0 + HCH < len) ? c0 + HCH : len;
   for (int64_t i = c0 + tid; i < c1; i += 256) {
     const int r = rows[b0 + i];
-    const int g = gq[r], h = hq[r];
+    const T g = gq[r], h = hq[r];
     const uint8_t* xb = Xb + (size_t)r * F + f0;
     for (int f = 0; f < nf; ++f) {
-      int* cell = hs + ((size_t)f * NBIN + xb[f]) * 3;
-      atomicAdd(cell, g); atomicAdd(cell + 1, h); atomicAdd(cell + 2, 1);
+      U* cell = reinterpret_cast<U*>(hs + ((size_t)f * NBIN + xb[f]) * 3);
+      atomicAdd(cell, (U)g); atomicAdd(cell + 1, (U)h); atomicAdd(cell + 2, (U)1);
     }
   }
   __syncthreads();
   for (int i = tid; i < nf * NBIN * 3; i += 256) {
-    const int v = hs[i];
+    const T v = hs[i];
     if (v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(hist) + (size_t)f0 * NBIN * 3 + i, (unsigned long long)(long long)v);
   }
 }
@@ -227,11 +248,18 @@ __device__ __forceinline__ double leaf_gain(double G, double H, double l1, doubl
   return t * t / (H + l2);
 }
 // best split of one leaf per workgroup (blockIdx.x = 0 / 1: the two children of a split in ONE launch): wave w takes
-// features w, w+16, ...; lane-sequential scan of the bins keeps the order fixed; ties go to the lower feature index
+// features w, w+16, ...; every lane evaluates the thresholds of its 4 bins, the wave keeps the best by (gain, evaluation
+// order); ties between features go to the lower feature index (LightGBM: SplitInfo::operator>).
+// A feature with a missing bin (nanbin[f] = its last bin) is tried both ways at every threshold: missing rows on the left
+// (default_left = 1) and on the right (default_left = 0, which also offers "every real value left | missing right").
+// Evaluation order = who wins among EQUAL gains (a leaf with few rows has many empty bins, i.e. runs of thresholds with
+// identical partitions): order 0 = lowest threshold first; order 1 = FeatureHistogram::FindBestThreshold: the
+// right-to-left scan first (highest threshold first, missing rows left), then the left-to-right scan (missing right),
+// a later candidate replaces an earlier one only if its gain is strictly larger.
 __global__ __launch_bounds__(1024) void split_kernel(const long long* __restrict__ hist0, const long long* __restrict__ hist1,
-                                                     int F, const int* __restrict__ nb,
+                                                     int F, const int* __restrict__ nb, const int* __restrict__ nanbin,
                                                      const unsigned char* __restrict__ used, double sg, double sh, double l1,
-                                                     double l2, int min_child, double min_hess, SplitInfo* out0) {
+                                                     double l2, int min_child, double min_hess, int order, SplitInfo* out0) {
   constexpr int NWV = 16;
   __shared__ SplitInfo best_w[NWV];
   const long long* __restrict__ hist = blockIdx.x == 0 ? hist0 : hist1;
@@ -239,8 +267,11 @@ __global__ __launch_bounds__(1024) void split_kernel(const long long* __restrict
   if (!hist) return;   // this child is not split further
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   SplitInfo best; best.gain = 0.0; best.feature = -1; best.bin = 0; best.glq = best.hlq = best.cl = 0; best.gq = best.hq = best.c = 0;
+  best.default_left = 1; best.pad = 0;
   for (int f = w; f < F; f += NWV) {
     const int nbf = nb[f];
+    const int nbn = nanbin[f];
+    const int nr = nbn >= 0 ? nbf - 1 : nbf;      // real bins
     if (!used[f] || nbf < 2) continue;
     const long long* h = hist + (size_t)f * NBIN * 3;
     // lane l owns bins 4l..4l+3: local sums, then an exclusive prefix over the lanes
@@ -259,36 +290,46 @@ __global__ __launch_bounds__(1024) void split_kernel(const long long* __restrict
       if (lane >= o) { pg += tg; phh += th; pc += tc; }
     }
     const long long TG = __shfl(pg, 63, 64), TH = __shfl(phh, 63, 64), TC = __shfl(pc, 63, 64);
+    long long NG = 0, NH = 0, NC = 0;             // the missing bin
+    if (nbn >= 0) { NG = h[nbn * 3]; NH = h[nbn * 3 + 1]; NC = h[nbn * 3 + 2]; }
     long long cg = pg - gs, ch = phh - hsum, cc = pc - cs;   // exclusive
     const double G = sg > 0.0 ? (double)TG / sg : 0.0, H = sh > 0.0 ? (double)TH / sh : 0.0;
     const double parent = leaf_gain(G, H, l1, l2);
-    double bg = 0.0; int bb_best = -1; long long bgl = 0, bhl = 0, bcl = 0;
+    double bg = 0.0; int bb_best = -1, bord = 0x7fffffff, bdl = 1; long long bgl = 0, bhl = 0, bcl = 0;
+    auto consider = [&](long long lg, long long lh, long long lc, int bb, int dl, int ord) {
+      const double GL = sg > 0.0 ? (double)lg / sg : 0.0, HL = sh > 0.0 ? (double)lh / sh : 0.0;
+      const double GR = G - GL, HR = H - HL;
+      const long long CR = TC - lc;
+      if (lc >= min_child && CR >= min_child && HL >= min_hess && HR >= min_hess) {
+        const double gain = leaf_gain(GL, HL, l1, l2) + leaf_gain(GR, HR, l1, l2) - parent;
+        if (gain > K_EPS && (bb_best < 0 || gain > bg || (gain == bg && ord < bord))) {
+          bg = gain; bb_best = bb; bord = ord; bdl = dl; bgl = lg; bhl = lh; bcl = lc;
+        }
+      }
+    };
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int bb = 4 * lane + k;
-      cg += g4[k]; ch += h4[k]; cc += c4[k];
-      if (bb < nbf - 1) {
-        const double GL = sg > 0.0 ? (double)cg / sg : 0.0, HL = sh > 0.0 ? (double)ch / sh : 0.0;
-        const double GR = G - GL, HR = H - HL;
-        const long long CR = TC - cc;
-        if (cc >= min_child && CR >= min_child && HL >= min_hess && HR >= min_hess) {
-          const double gain = leaf_gain(GL, HL, l1, l2) + leaf_gain(GR, HR, l1, l2) - parent;
-          if (gain > K_EPS && gain > bg) { bg = gain; bb_best = bb; bgl = cg; bhl = ch; bcl = cc; }
-        }
+      cg += g4[k]; ch += h4[k]; cc += c4[k];            // sums of the real bins <= bb (the missing bin is the last one)
+      if (nbn < 0) {
+        if (bb < nr - 1) consider(cg, ch, cc, bb, 1, order ? (nr - 2 - bb) : bb);
+      } else {
+        if (bb < nr - 1) consider(cg + NG, ch + NH, cc + NC, bb, 1, order ? (nr - 2 - bb) : 2 * bb);    // missing left
+        if (bb < nr) consider(cg, ch, cc, bb, 0, order ? (1000 + bb) : 2 * bb + 1);                    // missing right
       }
     }
-    // first maximum in bin order: larger gain wins, ties go to the lower bin
+    // larger gain wins, equal gains: the earlier candidate of the evaluation order
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const double og = __shfl_xor(bg, o, 64);
-      const int ob = __shfl_xor(bb_best, o, 64);
+      const int ob = __shfl_xor(bb_best, o, 64), oo = __shfl_xor(bord, o, 64), od = __shfl_xor(bdl, o, 64);
       const long long ogl = __shfl_xor(bgl, o, 64), ohl = __shfl_xor(bhl, o, 64), ocl = __shfl_xor(bcl, o, 64);
-      const bool take = ob >= 0 && (bb_best < 0 || og > bg || (og == bg && ob < bb_best));
-      if (take) { bg = og; bb_best = ob; bgl = ogl; bhl = ohl; bcl = ocl; }
+      const bool take = ob >= 0 && (bb_best < 0 || og > bg || (og == bg && oo < bord));
+      if (take) { bg = og; bb_best = ob; bord = oo; bdl = od; bgl = ogl; bhl = ohl; bcl = ocl; }
     }
     if (bb_best >= 0 && (best.feature < 0 || bg > best.gain)) {   // features ascending within the wave: ties keep the lower one
       best.gain = bg; best.feature = f; best.bin = bb_best; best.glq = bgl; best.hlq = bhl; best.cl = bcl;
-      best.gq = TG; best.hq = TH; best.c = TC;
+      best.gq = TG; best.hq = TH; best.c = TC; best.default_left = bdl;
     }
   }
   if (lane == 0) best_w[w] = best;
@@ -303,10 +344,14 @@ __global__ __launch_bounds__(1024) void split_kernel(const long long* __restrict
   }
 }
 
+// left = bin <= threshold bin; the rows of the feature's missing bin follow the node's default direction
 __global__ void part_flags_kernel(const uint8_t* __restrict__ Xb, int F, const int* __restrict__ rows, int64_t b0, int64_t len,
-                                  int f, int bin, int* flags) {
+                                  int f, int bin, int nanbin, int default_left, int* flags) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < len) flags[i] = Xb[(size_t)rows[b0 + i] * F + f] <= bin ? 1 : 0;
+  if (i < len) {
+    const int x = Xb[(size_t)rows[b0 + i] * F + f];
+    flags[i] = (x == nanbin) ? default_left : (x <= bin ? 1 : 0);
+  }
 }
 __global__ void part_scatter_kernel(const int* __restrict__ rows, int64_t b0, int64_t len, const int* __restrict__ flags,
                                     const int* __restrict__ scan, int64_t n_left, int* out) {
@@ -320,8 +365,9 @@ __global__ void copy_int_kernel(const int* __restrict__ src, int* dst, int64_t b
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < len) dst[b0 + i] = src[b0 + i];
 }
-__global__ void sum_leaf_kernel(const int* __restrict__ rows, int64_t b0, int64_t len, const int* __restrict__ gq,
-                                const int* __restrict__ hq, long long* out) {
+template <typename T>
+__global__ void sum_leaf_kernel(const int* __restrict__ rows, int64_t b0, int64_t len, const T* __restrict__ gq,
+                                const T* __restrict__ hq, long long* out) {
   long long g = 0, h = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x) {
     const int r = rows[b0 + i];
@@ -338,14 +384,20 @@ __global__ void add_leaf_kernel(const int* __restrict__ rows, int64_t b0, int64_
   if (i < len) score[rows[b0 + i]] += v;
 }
 // the new tree on binned rows (validation set): children >= 0 node, < 0 => ~leaf
+// (bin[node] carries the threshold bin in its low 16 bits, default_left in bit 16)
 __global__ void tree_add_kernel(const uint8_t* __restrict__ Xb, int64_t n, int F, const int* __restrict__ feat,
                                 const int* __restrict__ bin, const int* __restrict__ lc, const int* __restrict__ rc,
-                                const double* __restrict__ leaf, int n_nodes, double* score) {
+                                const double* __restrict__ leaf, const int* __restrict__ nanbin, int n_nodes, double* score) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int node = n_nodes > 0 ? 0 : -1;
   const uint8_t* x = Xb + (size_t)i * F;
-  while (node >= 0) node = x[feat[node]] <= bin[node] ? lc[node] : rc[node];
+  while (node >= 0) {
+    const int f = feat[node], b = bin[node];
+    const int v = x[f];
+    const bool left = (v == nanbin[f]) ? ((b >> 16) & 1) != 0 : v <= (b & 0xffff);
+    node = left ? lc[node] : rc[node];
+  }
   score[i] += leaf[~node];
 }
 
@@ -385,7 +437,7 @@ __global__ __launch_bounds__(64) void ndcg_kernel(const float* __restrict__ labe
 uint64_t splitmix64_h(uint64_t x) { return rihip_splitmix64(x); }
 
 struct Tree {
-  std::vector<int> feat, bin, lc, rc; std::vector<long long> cnt_int;
+  std::vector<int> feat, bin, lc, rc, dtype; std::vector<long long> cnt_int;   // dtype: LightGBM decision_type per node
   std::vector<double> thr, gain, leaf, int_val, int_w, leaf_w; std::vector<long long> leaf_cnt;
 };
 
@@ -402,7 +454,7 @@ struct Dataset {
 };
 
 int make_dataset(Dataset* D, const float* X, const float* y, const int32_t* groups, int64_t n, int F, int ng,
-                 const double* d_ub, const int* d_nb, int nk, hipStream_t st) {
+                 const double* d_ub, const int* d_nb, const int* d_nanbin, int nk, hipStream_t st) {
   D->n = n; D->ng = ng;
   std::vector<int64_t> off(ng + 1, 0);
   std::vector<int> ob(ng), oe(ng);
@@ -429,7 +481,7 @@ int make_dataset(Dataset* D, const float* X, const float* y, const int32_t* grou
   TCHK(hipMemcpyAsync(D->goff32b, ob.data(), sizeof(int) * ng, hipMemcpyHostToDevice, st));
   TCHK(hipMemcpyAsync(D->goff32e, oe.data(), sizeof(int) * ng, hipMemcpyHostToDevice, st));
   TCHK(hipStreamSynchronize(st));
-  hipLaunchKernelGGL(bin_rows_kernel, dim3((unsigned)((n * F + 255) / 256)), dim3(256), 0, st, X, n, F, d_ub, d_nb, D->Xb);
+  hipLaunchKernelGGL(bin_rows_kernel, dim3((unsigned)((n * F + 255) / 256)), dim3(256), 0, st, X, n, F, d_ub, d_nb, d_nanbin, D->Xb);
   TCHK(hipGetLastError());
   TCHK(rocprim::segmented_radix_sort_pairs(nullptr, D->temp_bytes, D->key, D->key2, D->val, D->sorted, (unsigned)n, (unsigned)ng,
                                            D->goff32b, D->goff32e, 0, 64, st));
@@ -475,7 +527,7 @@ std::string tree_to_text(const Tree& t, int index, double shrinkage) {
     ints("split_feature", t.feat);
     dbl("split_gain", t.gain);
     dbl("threshold", t.thr);
-    ints("decision_type", std::vector<int>(t.feat.size(), 2));
+    ints("decision_type", t.dtype);
     ints("left_child", t.lc);
     ints("right_child", t.rc);
   }
@@ -505,9 +557,17 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
                 RIHIP_ERR_ARG, "lambdamart_train: num_leaves in [2,128], max_bin in [2,255]");
   RIHIP_REQUIRE(p->truncation_level >= 1 && p->truncation_level <= MAX_T, RIHIP_ERR_ARG, "lambdamart_train: truncation_level in [1,%d]", MAX_T);
   RIHIP_REQUIRE(p->n_eval_at >= 1 && p->n_eval_at <= 8 && p->n_label_gain >= 2 && p->n_label_gain <= 32, RIHIP_ERR_ARG, "lambdamart_train: eval_at / label_gain sizes");
+  RIHIP_REQUIRE(p->hist_bits == 0 || p->hist_bits == 20 || p->hist_bits == 40, RIHIP_ERR_ARG, "lambdamart_train: hist_bits = 20 or 40");
   hipStream_t st = (hipStream_t)stream;
   const bool has_valid = Xv && yv && groups_v && nv > 0 && ngv > 0;
   const int nk = p->n_eval_at;
+  // 2^40 levels: the sums of n values stay below 2^62 (fewer levels for more than 2^22 rows)
+  int bits = p->hist_bits == 40 ? 40 : 20;
+  if (bits == 40) { int lg = 0; while ((1ll << lg) < n) ++lg; if (62 - lg < bits) bits = 62 - lg; }
+  const bool wide = bits > 20;
+  const double qlevels = ldexp(1.0, bits);
+  const bool use_missing = p->use_missing != 0;
+  const int split_order = p->split_order != 0 ? 1 : 0;
 
   // ---- bin upper bounds from a strided sample (host)
   const int64_t step = std::max<int64_t>(1, (n + p->bin_sample - 1) / p->bin_sample);
@@ -516,19 +576,21 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
   TCHK(hipMemcpy2DAsync(sample.data(), sizeof(float) * F, X, sizeof(float) * F * step, sizeof(float) * F, ns, hipMemcpyDeviceToHost, st));
   TCHK(hipStreamSynchronize(st));
   std::vector<double> ub((size_t)F * NBIN, INFINITY);
-  std::vector<int> nb(F, 1);
+  std::vector<int> nb(F, 1), nanbin(F, -1);
   {
     std::vector<double> col(ns), u; std::vector<int64_t> c;
     for (int f = 0; f < F; ++f) {
       size_t m = 0;
       for (int64_t i = 0; i < ns; ++i) { const double v = (double)sample[(size_t)i * F + f]; if (v == v) col[m++] = v; }
+      const bool has_nan = use_missing && m < (size_t)ns;     // LightGBM: missing type NaN iff the bin sample holds one
+      const int max_real = has_nan ? p->max_bin - 1 : p->max_bin;   // the missing rows take the last bin
       std::sort(col.begin(), col.begin() + m);
       u.clear(); c.clear();
       for (size_t i = 0; i < m; ++i) { if (u.empty() || col[i] != u.back()) { u.push_back(col[i]); c.push_back(1); } else c.back()++; }
       double* dst = ub.data() + (size_t)f * NBIN;
       int k = 0;
       if (u.size() > 1) {
-        if ((int)u.size() <= p->max_bin) {
+        if ((int)u.size() <= max_real) {
           for (size_t i = 0; i + 1 < u.size(); ++i) dst[k++] = (u[i] + u[i + 1]) * 0.5;
         } else {
           std::vector<int64_t> cum(c.size());
@@ -536,8 +598,8 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
           for (size_t i = 0; i < c.size(); ++i) { run += c[i]; cum[i] = run; }
           const int64_t tot = run;
           int64_t last = -1;
-          for (int b = 1; b < p->max_bin; ++b) {
-            const int64_t want = (tot * b + p->max_bin - 1) / p->max_bin;
+          for (int b = 1; b < max_real; ++b) {
+            const int64_t want = (tot * b + max_real - 1) / max_real;
             int64_t i = std::lower_bound(cum.begin(), cum.end(), want) - cum.begin();
             i = std::min<int64_t>(i, (int64_t)u.size() - 2);
             if (i > last) { dst[k++] = (u[i] + u[i + 1]) * 0.5; last = i; }
@@ -545,12 +607,15 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
         }
       }
       dst[k++] = INFINITY;
+      if (has_nan) { nanbin[f] = k; dst[k++] = NAN; }
       nb[f] = k;
     }
   }
-  double* d_ub = nullptr; int* d_nb = nullptr; double* d_gain = nullptr; int* d_ks = nullptr;
+  double* d_ub = nullptr; int* d_nb = nullptr; double* d_gain = nullptr; int* d_ks = nullptr; int* d_nanbin = nullptr;
   TCHK(hipMalloc((void**)&d_ub, sizeof(double) * ub.size()));
   TCHK(hipMalloc((void**)&d_nb, sizeof(int) * F));
+  TCHK(hipMalloc((void**)&d_nanbin, sizeof(int) * F));
+  TCHK(hipMemcpy(d_nanbin, nanbin.data(), sizeof(int) * F, hipMemcpyHostToDevice));
   TCHK(hipMalloc((void**)&d_gain, sizeof(double) * p->n_label_gain));
   TCHK(hipMalloc((void**)&d_ks, sizeof(int) * nk));
   TCHK(hipMemcpy(d_ub, ub.data(), sizeof(double) * ub.size(), hipMemcpyHostToDevice));
@@ -559,21 +624,22 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
   TCHK(hipMemcpy(d_ks, p->eval_at, sizeof(int) * nk, hipMemcpyHostToDevice));
 
   Dataset T, V;
-  int rc = make_dataset(&T, X, y, groups, n, F, ng, d_ub, d_nb, nk, st);
-  if (rc == RIHIP_OK && has_valid) rc = make_dataset(&V, Xv, yv, groups_v, nv, F, ngv, d_ub, d_nb, nk, st);
-  if (rc) { T.release(); V.release(); hipFree(d_ub); hipFree(d_nb); hipFree(d_gain); hipFree(d_ks); return rc; }
+  int rc = make_dataset(&T, X, y, groups, n, F, ng, d_ub, d_nb, d_nanbin, nk, st);
+  if (rc == RIHIP_OK && has_valid) rc = make_dataset(&V, Xv, yv, groups_v, nv, F, ngv, d_ub, d_nb, d_nanbin, nk, st);
+  if (rc) { T.release(); V.release(); hipFree(d_ub); hipFree(d_nb); hipFree(d_nanbin); hipFree(d_gain); hipFree(d_ks); return rc; }
 
   // ---- training scratch
   const int NL = p->num_leaves;
   const size_t HSZ = (size_t)F * NBIN * 3;
   double *ls = nullptr, *hs = nullptr, *lam = nullptr, *hes = nullptr, *d_leafv = nullptr;
-  int *gq = nullptr, *hq = nullptr, *rowsA = nullptr, *rowsB = nullptr, *flags = nullptr, *scan = nullptr;
+  void *gq = nullptr, *hq = nullptr;      // int32 (2^20 levels) or int64 (up to 2^40 levels) per row
+  int *rowsA = nullptr, *rowsB = nullptr, *flags = nullptr, *scan = nullptr;
   int *d_feat = nullptr, *d_bin = nullptr, *d_lc = nullptr, *d_rc = nullptr;
   long long* hist = nullptr; long long* d_sum = nullptr; unsigned long long* d_mx = nullptr; unsigned char* d_used = nullptr;
   SplitInfo* d_split = nullptr; void* scan_tmp = nullptr; size_t scan_bytes = 0;
   hipMalloc((void**)&ls, sizeof(double) * n); hipMalloc((void**)&hs, sizeof(double) * n);
   hipMalloc((void**)&lam, sizeof(double) * n); hipMalloc((void**)&hes, sizeof(double) * n);
-  hipMalloc((void**)&gq, sizeof(int) * n); hipMalloc((void**)&hq, sizeof(int) * n);
+  hipMalloc(&gq, (wide ? 8 : 4) * (size_t)n); hipMalloc(&hq, (wide ? 8 : 4) * (size_t)n);
   hipMalloc((void**)&rowsA, sizeof(int) * n); hipMalloc((void**)&rowsB, sizeof(int) * n);
   hipMalloc((void**)&flags, sizeof(int) * n); hipMalloc((void**)&scan, sizeof(int) * n);
   hipMalloc((void**)&hist, sizeof(long long) * HSZ * (size_t)NL); hipMalloc((void**)&d_sum, sizeof(long long) * 2);
@@ -588,7 +654,8 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
   static bool granted = false;
   if (!granted) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lambdarank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_GROUP * 9 + 64);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FCH * NBIN * 3 * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hist_kernel<int>), hipFuncAttributeMaxDynamicSharedMemorySize, FCH * NBIN * 3 * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hist_kernel<long long>), hipFuncAttributeMaxDynamicSharedMemorySize, FCH * NBIN * 3 * 4);
     granted = true;
   }
 
@@ -596,9 +663,15 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
     TCHK(hipMemsetAsync(dst, 0, sizeof(long long) * HSZ, st));
     if (len <= 0) return RIHIP_OK;
     const unsigned nchunk = (unsigned)((len + HCH - 1) / HCH);
-    for (int f0 = 0; f0 < F; f0 += FCH) {
-      const int nf = std::min(FCH, F - f0);
-      hipLaunchKernelGGL(hist_kernel, dim3(nchunk), dim3(256), (size_t)nf * NBIN * 3 * 4, st, T.Xb, F, rows, b0, len, gq, hq, f0, nf, dst);
+    const int fch = wide ? FCH / 2 : FCH;     // the same 96 KB of LDS with 8-byte cells
+    for (int f0 = 0; f0 < F; f0 += fch) {
+      const int nf = std::min(fch, F - f0);
+      if (wide)
+        hipLaunchKernelGGL(hist_kernel<long long>, dim3(nchunk), dim3(256), (size_t)nf * NBIN * 3 * 8, st, T.Xb, F, rows, b0, len,
+                           (const long long*)gq, (const long long*)hq, f0, nf, dst);
+      else
+        hipLaunchKernelGGL(hist_kernel<int>, dim3(nchunk), dim3(256), (size_t)nf * NBIN * 3 * 4, st, T.Xb, F, rows, b0, len,
+                           (const int*)gq, (const int*)hq, f0, nf, dst);
     }
     TCHK(hipGetLastError());
     return RIHIP_OK;
@@ -606,8 +679,8 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
   double sg = 0.0, sh = 0.0;
   // best splits of up to two leaves (the children of a split) in one launch; a null histogram = leaf not tried
   auto find_splits = [&](const long long* h0, const long long* h1, SplitInfo* slots) {
-    hipLaunchKernelGGL(split_kernel, dim3(h1 ? 2 : 1), dim3(1024), 0, st, h0, h1, F, d_nb, d_used, sg, sh, p->reg_alpha,
-                       p->reg_lambda, p->min_child_samples, p->min_sum_hessian, slots);
+    hipLaunchKernelGGL(split_kernel, dim3(h1 ? 2 : 1), dim3(1024), 0, st, h0, h1, F, d_nb, d_nanbin, d_used, sg, sh, p->reg_alpha,
+                       p->reg_lambda, p->min_child_samples, p->min_sum_hessian, split_order, slots);
   };
   SplitInfo* h_split = nullptr;   // pinned: the per-split read-back is on the critical path of the tree growth
   if (hipHostMalloc((void**)&h_split, sizeof(SplitInfo) * 2) != hipSuccess) h_split = nullptr;
@@ -652,8 +725,10 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
     unsigned long long mxb[2];
     if (hipMemcpyAsync(mxb, d_mx, sizeof(mxb), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rihip_set_error("lambdamart_train: gradient pass failed: %s", hipGetErrorString(hipGetLastError())); rc = RIHIP_ERR_HIP; break; }
     double gm, hm; memcpy(&gm, &mxb[0], 8); memcpy(&hm, &mxb[1], 8);
-    sg = gm > 0.0 ? QLEVELS / gm : 0.0; sh = hm > 0.0 ? QLEVELS / hm : 0.0;
-    hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, lam, hes, n, sg, sh, gq, hq);
+    sg = gm > 0.0 ? qlevels / gm : 0.0; sh = hm > 0.0 ? qlevels / hm : 0.0;
+    if (wide) hipLaunchKernelGGL(quantize_kernel<long long>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, lam, hes, n, sg, sh,
+                                 (long long*)gq, (long long*)hq);
+    else hipLaunchKernelGGL(quantize_kernel<int>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, lam, hes, n, sg, sh, (int*)gq, (int*)hq);
     // ---- features of this tree
     {
       std::vector<std::pair<uint64_t, int>> hv(F);
@@ -689,7 +764,8 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
       else {
         long long sums[2] = {0, 0};
         hipMemsetAsync(d_sum, 0, sizeof(long long) * 2, st);
-        hipLaunchKernelGGL(sum_leaf_kernel, dim3(256), dim3(256), 0, st, rowsA, 0, n, gq, hq, d_sum);
+        if (wide) hipLaunchKernelGGL(sum_leaf_kernel<long long>, dim3(256), dim3(256), 0, st, rowsA, 0, n, (const long long*)gq, (const long long*)hq, d_sum);
+        else hipLaunchKernelGGL(sum_leaf_kernel<int>, dim3(256), dim3(256), 0, st, rowsA, 0, n, (const int*)gq, (const int*)hq, d_sum);
         hipMemcpyAsync(sums, d_sum, sizeof(sums), hipMemcpyDeviceToHost, st);
         hipStreamSynchronize(st);
         root.gq = sums[0]; root.hq = sums[1]; root.c = n;
@@ -704,8 +780,18 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
       Leaf par = leaves[pick];
       const SplitInfo sp = par.s;
       const int node = (int)tree.feat.size();
-      tree.feat.push_back(sp.feature); tree.bin.push_back(sp.bin);
-      tree.thr.push_back(ub[(size_t)sp.feature * NBIN + sp.bin]); tree.gain.push_back(sp.gain);
+      const int f_nan = nanbin[sp.feature];
+      tree.feat.push_back(sp.feature); tree.bin.push_back(sp.bin | (sp.default_left ? (1 << 16) : 0));
+      {
+        // "every real value left | missing right" splits at the last real bin, whose bound is +inf: written as the largest
+        // double (x <= DBL_MAX holds for every finite x; the text format has no inf)
+        const double th = ub[(size_t)sp.feature * NBIN + sp.bin];
+        tree.thr.push_back(th == INFINITY ? 1.7976931348623157e308 : th);
+      }
+      // decision_type: bit 1 = default_left, bits 2-3 = missing type (0 none, 2 NaN); a feature without a missing bin is
+      // written like LightGBM writes it: default left, missing none (2)
+      tree.dtype.push_back(f_nan >= 0 ? (8 | (sp.default_left ? 2 : 0)) : 2);
+      tree.gain.push_back(sp.gain);
       tree.lc.push_back(~pick); tree.rc.push_back(~(int)leaves.size());
       tree.cnt_int.push_back(sp.c);
       {
@@ -719,7 +805,7 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
       // partition the rows of the leaf (stable): left = bin <= threshold bin
       {
         const unsigned g = (unsigned)((par.len + 255) / 256);
-        hipLaunchKernelGGL(part_flags_kernel, dim3(g), dim3(256), 0, st, T.Xb, F, rowsA, par.b, par.len, sp.feature, sp.bin, flags);
+        hipLaunchKernelGGL(part_flags_kernel, dim3(g), dim3(256), 0, st, T.Xb, F, rowsA, par.b, par.len, sp.feature, sp.bin, f_nan, sp.default_left, flags);
         size_t tb = scan_bytes;
         if (rocprim::exclusive_scan(scan_tmp, tb, flags, scan, 0, (size_t)par.len, rocprim::plus<int>(), st) != hipSuccess) { rihip_set_error("lambdamart_train: scan failed"); rc = RIHIP_ERR_HIP; break; }
         hipLaunchKernelGGL(part_scatter_kernel, dim3(g), dim3(256), 0, st, rowsA, par.b, par.len, flags, scan, (int64_t)sp.cl, rowsB);
@@ -746,8 +832,8 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
         // (grid of 2 whenever the right child is tried: a null left histogram makes workgroup 0 return at once)
         const long long* hL = tryL ? hist + (size_t)L.slot * HSZ : nullptr;
         const long long* hR = tryR ? hist + (size_t)R.slot * HSZ : nullptr;
-        if (tryR) hipLaunchKernelGGL(split_kernel, dim3(2), dim3(1024), 0, st, hL, hR, F, d_nb, d_used, sg, sh, p->reg_alpha,
-                                     p->reg_lambda, p->min_child_samples, p->min_sum_hessian, d_split);
+        if (tryR) hipLaunchKernelGGL(split_kernel, dim3(2), dim3(1024), 0, st, hL, hR, F, d_nb, d_nanbin, d_used, sg, sh, p->reg_alpha,
+                                     p->reg_lambda, p->min_child_samples, p->min_sum_hessian, split_order, d_split);
         else find_splits(hL, nullptr, d_split);
         rc = read_splits(two, 2);
         if (rc) break;
@@ -781,7 +867,7 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
       }
       hipMemcpyAsync(d_leafv, tree.leaf.data(), sizeof(double) * nl, hipMemcpyHostToDevice, st);
       hipLaunchKernelGGL(tree_add_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, V.Xb, nv, F, d_feat, d_bin, d_lc, d_rc,
-                         d_leafv, nn, V.score);
+                         d_leafv, d_nanbin, nn, V.score);
       hipStreamSynchronize(st);   // the host vectors above must outlive the copies
     }
     if (hipGetLastError() != hipSuccess) { rihip_set_error("lambdamart_train: tree %d launch failed", it); rc = RIHIP_ERR_HIP; break; }
@@ -792,7 +878,7 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
   hipFree(scan); hipFree(hist); hipFree(d_sum); hipFree(d_mx); hipFree(d_used); hipFree(d_split); hipFree(scan_tmp);
   if (h_split) hipHostFree(h_split);
   hipFree(d_feat); hipFree(d_bin); hipFree(d_lc); hipFree(d_rc); hipFree(d_leafv);
-  T.release(); V.release(); hipFree(d_ub); hipFree(d_nb); hipFree(d_gain); hipFree(d_ks);
+  T.release(); V.release(); hipFree(d_ub); hipFree(d_nb); hipFree(d_nanbin); hipFree(d_gain); hipFree(d_ks);
   if (rc) return rc;
 
   // ---- LightGBM text model (Booster.save_model layout, src/models/ranker.py:203-209)

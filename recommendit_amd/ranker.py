@@ -94,13 +94,28 @@ class LightGBMRanker:
     # -- training (ranker.py:52-155) -----------------------------------------------------------
     def train(self, train_df: pd.DataFrame, feature_cols: List[str], label_col: str = "label",
               query_col: str = "query_id", valid_df: Optional[pd.DataFrame] = None, verbose_eval: int = 50,
-              backend: Optional[str] = None, seed: int = 2):
+              backend: Optional[str] = None, seed: int = 2, hist_dtype: str = "int20", use_missing: bool = False,
+              split_order: str = "low"):
         """backend: "hip" = the library's GPU trainer, "lightgbm" = the real package (as the reference), None = lightgbm
         when importable, else hip.  Returns the evals_result dict of lgb.record_evaluation:
-        {"train": {"ndcg@5": [...], ...}, "valid": {...}}."""
+        {"train": {"ndcg@5": [...], ...}, "valid": {...}}.
+
+        Fidelity switches of the hip backend towards LightGBM's defaults (parity with the real package stays unpinned --
+        it is not importable here; each switch is pinned to its own branch of oracle/lambdamart_np.py):
+          hist_dtype  "int20": gradients quantised to 2^20 levels (LightGBM's use_quantized_grad idea; the default here);
+                      "float": float-histogram fidelity -- 2^-40 fixed point, finer than the float32 rounding of a
+                      gradient by 2^16, and still independent of summation order;
+          use_missing True: NaN is a value of its own (missing bin, learned default direction per node, the text model
+                      carries missing type NaN) instead of being read as 0.0;
+          split_order "lightgbm": equal-gain thresholds resolved in FeatureHistogram::FindBestThreshold's scan order (the
+                      highest threshold of a run of empty bins) instead of the lowest."""
         backend = backend or ("lightgbm" if LGB_AVAILABLE else "hip")
         if backend == "hip":
-            return self._train_hip(train_df, feature_cols, label_col, query_col, valid_df, verbose_eval, seed)
+            if hist_dtype not in ("int20", "float", "int40") or split_order not in ("low", "lightgbm"):
+                raise ValueError("hist_dtype in {'int20', 'float'}, split_order in {'low', 'lightgbm'}")
+            return self._train_hip(train_df, feature_cols, label_col, query_col, valid_df, verbose_eval, seed,
+                                   40 if hist_dtype in ("float", "int40") else 20, bool(use_missing),
+                                   1 if split_order == "lightgbm" else 0)
         if not LGB_AVAILABLE:
             raise ImportError("lightgbm is required for training. Install with: pip install lightgbm "
                               "(load()/predict() do not need it)")
@@ -137,7 +152,8 @@ class LightGBMRanker:
         self._trained = True
         return evals_result
 
-    def _train_hip(self, train_df, feature_cols, label_col, query_col, valid_df, verbose_eval, seed):
+    def _train_hip(self, train_df, feature_cols, label_col, query_col, valid_df, verbose_eval, seed, hist_bits=20,
+                   use_missing=False, split_order=0):
         lib = L.lib()
         self.feature_names = list(feature_cols)
         dev = L.device()
@@ -159,6 +175,7 @@ class LightGBMRanker:
         prm.lambdarank_norm, prm.bin_sample = 1, 200000
         prm.reg_alpha, prm.reg_lambda, prm.feature_fraction, prm.min_sum_hessian, prm.sigmoid = 0.1, 0.1, 0.8, 1e-3, 1.0
         prm.seed = seed
+        prm.hist_bits, prm.use_missing, prm.split_order = int(hist_bits), 1 if use_missing else 0, int(split_order)
         prm.n_eval_at = len(self.eval_at)
         for i, k in enumerate(self.eval_at):
             prm.eval_at[i] = int(k)

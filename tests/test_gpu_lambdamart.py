@@ -144,3 +144,101 @@ def test_large_query_groups_and_many_bins():
         np.testing.assert_array_equal(a["threshold"], b["threshold"])
         np.testing.assert_allclose(a["leaf_value"], b["leaf_value"], rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(res["train"]["ndcg@10"], [h["train"][0] for h in o["history"]], atol=1e-9)
+
+
+def _xy(df, cols):
+    return (df[cols].values.astype(np.float32), df["label"].values, df.groupby("query_id", sort=False).size().values)
+
+
+def _same_trees(m, o, leaf_rtol=1e-9, exact_thr=True):
+    assert len(m["trees"]) == len(o["trees"])
+    for t, (a, b) in enumerate(zip(m["trees"], o["trees"])):
+        assert a["num_leaves"] == b["num_leaves"], t
+        np.testing.assert_array_equal(a["split_feature"], b["split_feature"], err_msg=f"tree {t}")
+        np.testing.assert_array_equal(a["left_child"], b["left_child"], err_msg=f"tree {t}")
+        np.testing.assert_array_equal(a["right_child"], b["right_child"], err_msg=f"tree {t}")
+        np.testing.assert_array_equal(a["decision_type"], b["decision_type"], err_msg=f"tree {t}")
+        if exact_thr:
+            np.testing.assert_array_equal(a["threshold"], b["threshold"], err_msg=f"tree {t}")
+        np.testing.assert_allclose(a["leaf_value"], b["leaf_value"], rtol=leaf_rtol, atol=1e-12, err_msg=f"tree {t}")
+
+
+def test_float_histogram_mode_vs_its_oracle_branches():
+    """hist_dtype="float" (2^-40 fixed point, order-independent) is (a) bit-identical to the oracle's int40 restatement
+    and (b) equal -- same splits, leaf values to 1e-7 -- to the oracle's FLOAT branch: unquantised gradients, f64
+    histogram sums in row order, thresholds found by LightGBM's two sequential scans (written from the published
+    FeatureHistogram::FindBestThreshold, not from the kernel).  lightgbm itself is absent: parity unpinned."""
+    from recommendit_amd import LightGBMRanker
+    rng = np.random.RandomState(5)
+    F = 10
+    tr = _ranking_set(rng, 120, (20, 60), F, grades=3)
+    cols = [f"f{i}" for i in range(F)]
+    prm = dict(num_leaves=15, n_estimators=5, learning_rate=0.1, eval_at=[5, 10])
+    rk = LightGBMRanker(**prm)
+    res = rk.train(tr, cols, backend="hip", hist_dtype="float")
+    m = _model_from_text(rk._text)
+    X, y, g = _xy(tr, cols)
+    _same_trees(m, LM.train(X, y, g, dict(prm, hist_dtype="int40"), feature_names=cols))
+    of = LM.train(X, y, g, dict(prm, hist_dtype="float"), feature_names=cols)
+    _same_trees(m, of, leaf_rtol=1e-7)
+    np.testing.assert_allclose(res["train"]["ndcg@10"], [h["train"][1] for h in of["history"]], atol=1e-9)
+    # and it is not the 2^20 mode: the leaf values differ from the quantised run at the 1e-6 level
+    rk20 = LightGBMRanker(**prm)
+    rk20.train(tr, cols, backend="hip")
+    m20 = _model_from_text(rk20._text)
+    assert any(not np.array_equal(a["leaf_value"], b["leaf_value"]) for a, b in zip(m["trees"], m20["trees"]))
+
+
+@pytest.mark.parametrize("order", ["low", "lightgbm"])
+@pytest.mark.parametrize("hist", ["int20", "float"])
+def test_missing_values_learn_a_default_direction(order, hist):
+    """use_missing=True with 15 % NaN: missing bin + default direction per node, trees identical to the oracle's
+    sequential-scan branch in both tie orders; the text model carries missing type NaN (decision_type 8 / 10) and the
+    HIP predictor routes NaN rows by it (scores equal to the oracle's walk of the same model)"""
+    from recommendit_amd import LightGBMRanker
+    rng = np.random.RandomState(6)
+    F = 9
+    tr = _ranking_set(rng, 100, (20, 50), F, grades=3)
+    cols = [f"f{i}" for i in range(F)]
+    X = tr[cols].values.astype(np.float32)
+    miss = rng.rand(*X.shape) < 0.15
+    miss[:, 2] = False                                   # one feature without any NaN: keeps decision_type 2
+    X[miss] = np.nan
+    X[:, 4] = np.where(rng.rand(len(X)) < 0.5, np.nan, X[:, 4])       # informative missingness
+    tr[cols] = X
+    prm = dict(num_leaves=15, n_estimators=4, learning_rate=0.1, eval_at=[5])
+    rk = LightGBMRanker(**prm)
+    rk.train(tr, cols, backend="hip", use_missing=True, split_order=order, hist_dtype=hist)
+    m = _model_from_text(rk._text)
+    Xf, y, g = _xy(tr, cols)
+    o = LM.train(Xf, y, g, dict(prm, use_missing=True, split_order=order, hist_dtype="int40" if hist == "float" else hist),
+                 feature_names=cols)
+    _same_trees(m, o)
+    dts = np.concatenate([t["decision_type"] for t in m["trees"]])
+    assert set(dts.tolist()) <= {2, 8, 10} and (dts == 8).any() and (dts == 10).any()
+    np.testing.assert_allclose(rk.predict(tr), G.predict_raw(m, Xf), rtol=0, atol=1e-12)
+    # without use_missing the same data trains as if NaN were 0.0 and every node is the plain decision_type 2
+    rk0 = LightGBMRanker(**prm)
+    rk0.train(tr, cols, backend="hip")
+    assert set(np.concatenate([t["decision_type"] for t in _model_from_text(rk0._text)["trees"]]).tolist()) == {2}
+
+
+def test_lightgbm_tie_order_keeps_the_highest_threshold_of_an_empty_run():
+    """few rows per leaf => runs of empty bins => equal gains: split_order="lightgbm" must pick the highest threshold of
+    the run (FindBestThreshold scans right-to-left with a strict '>'), "low" the lowest; both equal their oracle branch"""
+    from recommendit_amd import LightGBMRanker
+    rng = np.random.RandomState(7)
+    F = 6
+    tr = _ranking_set(rng, 40, (15, 30), F, grades=3)
+    cols = [f"f{i}" for i in range(F)]
+    prm = dict(num_leaves=15, n_estimators=3, learning_rate=0.1, eval_at=[5])
+    X, y, g = _xy(tr, cols)
+    thr = {}
+    for order in ("low", "lightgbm"):
+        rk = LightGBMRanker(**prm)
+        rk.train(tr, cols, backend="hip", split_order=order)
+        m = _model_from_text(rk._text)
+        _same_trees(m, LM.train(X, y, g, dict(prm, split_order=order), feature_names=cols))
+        thr[order] = np.concatenate([t["threshold"] for t in m["trees"]])
+    assert (thr["lightgbm"][: len(thr["low"])] >= thr["low"][: len(thr["lightgbm"])]).mean() > 0.5
+    assert not np.array_equal(thr["lightgbm"], thr["low"])
