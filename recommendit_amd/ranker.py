@@ -101,7 +101,7 @@ class LightGBMRanker:
         {"train": {"ndcg@5": [...], ...}, "valid": {...}}.
 
         Fidelity switches of the hip backend towards LightGBM's defaults (parity with the real package stays unpinned --
-        it is not importable here; each switch is pinned to its own branch of oracle/lambdamart_np.py):
+        it is not importable here; each switch is pinned to its own branch of the NumPy restatement the tests use):
           hist_dtype  "int20": gradients quantised to 2^20 levels (LightGBM's use_quantized_grad idea; the default here);
                       "float": float-histogram fidelity -- 2^-40 fixed point, finer than the float32 rounding of a
                       gradient by 2^16, and still independent of summation order;
