@@ -26,7 +26,8 @@ NOT from the kernel (which evaluates every threshold in parallel from prefix sum
   * ``use_missing=True``: a feature whose bin sample holds a NaN gets a last "missing" bin (missing type NaN); the
     threshold search runs LightGBM's two sequential scans -- right-to-left accumulating the RIGHT side (the missing rows
     fall to the left: default_left) and left-to-right accumulating the LEFT side (missing rows right), the second scan
-    also offering "every real value left | missing right";
+    also offering "every real value left | missing right" (its mirror image "missing rows alone left | every real value
+    right" has the same gain up to rounding and is not offered: which of the two a float comparison prefers is noise);
   * ``split_order="lightgbm"``: a candidate replaces the incumbent only if its gain is strictly larger, in LightGBM's
     scan order (right-to-left first), so equal gains -- runs of empty bins -- keep the HIGHEST threshold; ``"low"`` keeps
     the lowest.  Across features the lower feature index wins a tie in both (SplitInfo::operator>).
@@ -232,6 +233,8 @@ def _best_split(hist: np.ndarray, nb: Sequence[int], used: np.ndarray, sg: float
         rev = []
         for t in range(nr - 1, 0, -1):
             rg += num(hist[f, t, 0]); rh += num(hist[f, t, 1]); rc += int(hist[f, t, 2])
+            if nbn >= 0 and (TC - rc) - int(hist[f, nbn, 2]) == 0:
+                continue    # the missing rows alone on the left: mirror image of the last left-to-right candidate, offered there
             rev.append((TG - rg, TH - rh, TC - rc, t - 1, True))
         # left-to-right (missing bin only): threshold t for t = 0 .. nr-1; left = real bins <= t
         fwd = []

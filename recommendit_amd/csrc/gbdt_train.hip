@@ -41,6 +41,11 @@
 
 #include <rocprim/rocprim.hpp>
 
+// No FMA contraction in this file: split gains are compared for EQUALITY (ties between thresholds with identical
+// partitions are resolved by evaluation order), so two evaluations of the same sums must round identically -- and like the
+// IEEE double arithmetic of the NumPy restatement the trees are compared against.
+#pragma clang fp contract(off)
+
 namespace {
 
 #define TCHK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { rihip_set_error("%s:%d %s", __FILE__, __LINE__, hipGetErrorString(_e)); return RIHIP_ERR_HIP; } } while (0)
@@ -314,7 +319,9 @@ __global__ __launch_bounds__(1024) void split_kernel(const long long* __restrict
       if (nbn < 0) {
         if (bb < nr - 1) consider(cg, ch, cc, bb, 1, order ? (nr - 2 - bb) : bb);
       } else {
-        if (bb < nr - 1) consider(cg + NG, ch + NH, cc + NC, bb, 1, order ? (nr - 2 - bb) : 2 * bb);    // missing left
+        // missing left -- only with at least one real row on the left: "missing rows alone | every real row" is the
+        // mirror image of the last missing-right candidate (equal gain up to rounding), offered once, there
+        if (bb < nr - 1 && cc > 0) consider(cg + NG, ch + NH, cc + NC, bb, 1, order ? (nr - 2 - bb) : 2 * bb);
         if (bb < nr) consider(cg, ch, cc, bb, 0, order ? (1000 + bb) : 2 * bb + 1);                    // missing right
       }
     }
