@@ -554,7 +554,7 @@ def leg_serve(model, X, n_users_local, dev, cpu):
     store._dev = (torch.rand((n_users_local + 1, 24), device=dev, generator=gg, dtype=torch.float64),
                   torch.rand((N + 1, 23), device=dev, generator=gg, dtype=torch.float64))
     pipe = GpuRecommendationPipeline(model, ivf, ranker, store, top_k_candidates=K_TOP, top_k_results=20)
-    nqs = 256
+    nqs = int(os.environ.get("RIHIP_SERVE_BATCH", "256"))
     uids = [torch.randint(1, n_users_local + 1, (nqs,), device=dev, generator=gg) for _ in range(3)]
     meds, bests, _ = timed_blocks(lambda i: pipe.recommend_batch(uids[i % 3]), 12)
     one = uids[0][:1]

@@ -12,12 +12,45 @@ import torch.distributed as dist
 
 
 def direct() -> bool:
-    """RIHIP_COLLECTIVES=direct (default) | ring.  The 8 GPUs of an MI355X node form a full xGMI mesh of point-to-point
+    """RIHIP_COLLECTIVES=rccl (default) | direct.  The 8 GPUs of an MI355X node form a full xGMI mesh of point-to-point
     links (7 x ~153 GB/s per GPU): every peer is ONE hop away.  "direct" runs the all-gather of tower outputs and the
     reduce-scatter of partial item gradients as equal-split all-to-alls (7 concurrent one-hop transfers of 1/W of the
-    data, then a local fixed-order sum) instead of RCCL's ring schedules (W-1 dependent steps); "ring" keeps
-    ncclAllGather / ncclReduceScatter.  Device tensors over RCCL only; the gloo rehearsal always takes the plain calls."""
-    return os.environ.get("RIHIP_COLLECTIVES", "direct") != "ring"
+    data, then a local fixed-order sum) instead of RCCL's own schedules for ncclAllGather / ncclReduceScatter.  Its
+    logic is covered by a CPU (gloo) test; it has never run on a multi-GPU node, which is why the library's own
+    collectives stay the default until a scaling run has compared the two."""
+    return os.environ.get("RIHIP_COLLECTIVES", "rccl") == "direct"
+
+
+def _direct_for(t: torch.Tensor, group) -> bool:
+    """one-hop forms: device tensors over RCCL when asked for; RIHIP_COLLECTIVES=direct_any also takes them for host
+    tensors over gloo (the CPU test of their logic)"""
+    mode = os.environ.get("RIHIP_COLLECTIVES", "rccl")
+    if dist.get_world_size(group) < 2:
+        return False
+    if mode == "direct_any":
+        return not _staged(t, group)
+    return mode == "direct" and t.is_cuda and not _staged(t, group)
+
+
+def _all_gather_direct(out: torch.Tensor, inp: torch.Tensor, group, async_op: bool):
+    """the same block goes to every peer (input replicated W times: 10 us of HBM copies at 4 MiB)"""
+    W = dist.get_world_size(group)
+    rep = inp.contiguous().unsqueeze(0).expand(W, *inp.shape).contiguous().view(W * inp.shape[0], *inp.shape[1:])
+    w = dist.all_to_all_single(out, rep, group=group, async_op=async_op)
+    return w if async_op else _Done()
+
+
+def _reduce_scatter_direct(out: torch.Tensor, inp: torch.Tensor, group, async_op: bool):
+    """slice p of every rank's partial goes straight to rank p, which adds the W slices in a fixed order (bitwise
+    reproducible, independent of any ring schedule)"""
+    W = dist.get_world_size(group)
+    recv = torch.empty_like(inp)
+    work = dist.all_to_all_single(recv, inp.contiguous(), group=group, async_op=True)
+    h = _DirectReduce(work, recv, out, W)
+    if async_op:
+        return h
+    h.wait()
+    return _Done()
 
 
 def _staged(t: torch.Tensor, group) -> bool:
@@ -47,12 +80,9 @@ def all_gather_into(out: torch.Tensor, inp: torch.Tensor, group=None, async_op: 
     async_op=True (RCCL only): returns a work handle; the collective runs on RCCL's stream, ordered after the kernels
     already queued on the current stream, and `handle.wait()` orders later kernels after it -- lets an all-gather
     that is only needed two kernels later overlap with the kernel in between."""
+    if _direct_for(inp, group):
+        return _all_gather_direct(out, inp, group, async_op)
     if inp.is_cuda and not _staged(inp, group) and async_op:
-        W = dist.get_world_size(group)
-        if direct() and W > 1:
-            # one-hop form: the same block goes to every peer (input replicated W times: 10 us of HBM copies at 4 MiB)
-            rep = inp.contiguous().unsqueeze(0).expand(W, *inp.shape).contiguous().view(W * inp.shape[0], *inp.shape[1:])
-            return dist.all_to_all_single(out, rep, group=group, async_op=True)
         return dist.all_gather_into_tensor(out, inp.contiguous(), group=group, async_op=True)
     _all_gather_sync(out, inp, group)
     return _Done()
@@ -94,18 +124,9 @@ def broadcast_(t: torch.Tensor, src: int = 0, group=None) -> None:
 def reduce_scatter_sum(out: torch.Tensor, inp: torch.Tensor, group=None, async_op: bool = False):
     """out = (sum over ranks of inp)[rank*n:(rank+1)*n], n = out.shape[0] (rows).  Same async contract as
     all_gather_into."""
+    if _direct_for(inp, group):
+        return _reduce_scatter_direct(out, inp, group, async_op)
     if inp.is_cuda and not _staged(inp, group):
-        W = dist.get_world_size(group)
-        if direct() and W > 1:
-            # one-hop form: slice p of every rank's partial goes straight to rank p, which adds the W slices in a fixed
-            # order (bitwise reproducible, independent of any ring schedule)
-            recv = torch.empty_like(inp)
-            work = dist.all_to_all_single(recv, inp.contiguous(), group=group, async_op=True)
-            h = _DirectReduce(work, recv, out, W)
-            if async_op:
-                return h
-            h.wait()
-            return _Done()
         w = dist.reduce_scatter_tensor(out, inp.contiguous(), group=group, async_op=async_op)
         return w if async_op else _Done()
     c = inp.detach().cpu().contiguous()          # gloo has no reduce_scatter: all-reduce on the host, keep own slice

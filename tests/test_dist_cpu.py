@@ -130,3 +130,41 @@ def test_two_rank_row_sharded_exchange(tmp_path):
     for r, p in enumerate(parts):
         np.testing.assert_allclose(p["acc"][1:], ref[1 + r::world], atol=1e-12)
         assert (p["acc"][0] == 0).all()
+
+
+def _direct_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["RIHIP_COLLECTIVES"] = "direct_any"     # the one-hop forms on host tensors over gloo
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from recommendit_amd.dist_utils import all_gather_into, reduce_scatter_sum
+    B, d = 5, 4
+    rng = np.random.RandomState(100 + rank)
+    mine = torch.from_numpy(rng.randn(B, d).astype(np.float32))
+    ids = torch.arange(rank * 7, rank * 7 + 6)
+    out = torch.empty((world * B, d)); out_ids = torch.empty((world * 6,), dtype=torch.int64)
+    all_gather_into(out, mine, async_op=True).wait()
+    all_gather_into(out_ids, ids)
+    part = torch.from_numpy(rng.randn(world * B, d).astype(np.float32))   # this rank's partial for ALL items
+    rs = torch.empty((B, d))
+    reduce_scatter_sum(rs, part, async_op=True).wait()
+    rs2 = torch.empty((B, d))
+    reduce_scatter_sum(rs2, part)
+    np.savez(os.path.join(out_dir, f"d{rank}.npz"), mine=mine.numpy(), gathered=out.numpy(), ids=out_ids.numpy(),
+             part=part.numpy(), rs=rs.numpy(), rs2=rs2.numpy())
+    dist.destroy_process_group()
+
+
+def test_one_hop_collectives_equal_the_native_ones(tmp_path):
+    """RIHIP_COLLECTIVES=direct: all-gather = replicated equal-split all-to-all; reduce-scatter = all-to-all + local
+    fixed-order sum (recommendit_amd/dist_utils.py) -- the logic, on 3 gloo ranks"""
+    world = 3
+    mp.spawn(_direct_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(tmp_path / f"d{r}.npz") for r in range(world)]
+    full = np.concatenate([p["mine"] for p in parts])
+    tot = sum(p["part"].astype(np.float64) for p in parts)
+    for r, p in enumerate(parts):
+        np.testing.assert_array_equal(p["gathered"], full)
+        np.testing.assert_array_equal(p["ids"], np.concatenate([np.arange(q * 7, q * 7 + 6) for q in range(world)]))
+        np.testing.assert_allclose(p["rs"], tot[r * 5:(r + 1) * 5], atol=1e-6)
+        np.testing.assert_array_equal(p["rs"], p["rs2"])
