@@ -733,6 +733,8 @@ extern "C" int rihip_tower_supported(int d, int hidden) {
          (d == 64 && hidden == 64) || (d == 32 && hidden == 128);
 }
 
+// tower3.hip: data + weight gradients of a tile in one kernel (d = hidden = 128); returns the slabs written (0: not covered)
+int rihip_launch_tower_bwd3(int d, int hidden, bool item, const TowerBwdArgs& a, int max_slabs, hipStream_t st);
 // tower_generic.hip: runtime-shape kernels behind the tuned instantiations
 bool rihip_tower_generic_ok(int d, int hidden);
 void rihip_launch_tower_fwd_generic(int d, int hidden, bool item, const TowerFwdArgs& a, hipStream_t st);
@@ -895,10 +897,17 @@ extern "C" int rihip_tower_backward_partial(const float* table, int64_t n_rows, 
     *n_slabs = nslab;
     return RIHIP_OK;
   }
-  {  // two-kernel backward (tower2.hip) for chip-filling batches; 1 = the fused 64-row-tile kernel
+  {  // chip-filling batches: the one-kernel backward (tower3.hip: data + weight gradients per tile, no gy / dPre round
+     // trip); RIHIP_TOWER_BWD = 4: that kernel at any size (tests), 3: the two-kernel form (tower2.hip) at any size,
+     // 5: the two-kernel form for chip-filling batches (the round-2 default), 1: the fused 64-row-tile kernel
     const char* ev = getenv("RIHIP_TOWER_BWD");
     const int which = ev ? atoi(ev) : 2;
-    if (((which == 2 && B >= 49152) || which == 3) && aligned16(W2) && aligned16(dX))
+    const int64_t nt32 = (B + 31) / 32;
+    if (((which == 2 && B >= 49152) || which == 4) && aligned16(W2) && aligned16(dX)) {
+      nslab = rihip_launch_tower_bwd3(d, hidden, item, a, (int)(nt32 < RIHIP_NCU ? nt32 : RIHIP_NCU), st);
+      if (nslab > 0 && dx_event) (void)hipEventRecord((hipEvent_t)dx_event, st);
+    }
+    if (nslab == 0 && (((which == 2 || which == 5) && B >= 49152) || which == 3) && aligned16(W2) && aligned16(dX))
       nslab = rihip_launch_tower_bwd2(d, hidden, item, a, act, st, (hipEvent_t)dx_event);
   }
   if (nslab == 0) {

@@ -80,14 +80,15 @@ def test_status_codes_not_aborts():
     from recommendit_amd import _lib
     l = _lib.lib()
     h = ctypes.c_void_p()
-    assert l.rihip_ip_index_create(48, ctypes.byref(h)) != 0 and b"unsupported" in l.rihip_last_error()
+    assert l.rihip_ip_index_create(48, ctypes.byref(h)) == 0 and l.rihip_ip_index_destroy(h) == 0   # any width up to 128
+    assert l.rihip_ip_index_create(200, ctypes.byref(h)) != 0 and b"unsupported" in l.rihip_last_error()
     assert l.rihip_gbdt_load_text(b"/nonexistent/model.txt", ctypes.byref(h)) != 0 and b"cannot open" in l.rihip_last_error()
     x = torch.zeros(8, device="cuda")
     assert l.rihip_adam_dense(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), 8, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0,
                               None, None, None) != 0  # step must be >= 1 when no device clock is given
     with pytest.raises(RuntimeError, match="no HIP kernel instantiation|unsupported"):
         from recommendit_amd import TwoTowerModel
-        TwoTowerModel(5, 5, embed_dim=48, hidden_dim=64).user_tower(torch.tensor([1]))
+        TwoTowerModel(5, 5, embed_dim=40, hidden_dim=64).user_tower(torch.tensor([1]))   # not a multiple of 16
 
 
 def test_multi_tensor_launches_equal_single_tensor_calls():

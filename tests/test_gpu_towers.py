@@ -36,13 +36,18 @@ def t(x):
     return torch.from_numpy(np.asarray(x)).to(dev())
 
 
-@pytest.fixture(params=["auto", "rows32"])
+@pytest.fixture(params=["auto", "rows32", "coop"])
 def fwd_kernel(request, monkeypatch):
-    """Both tower-kernel families on every shape: "auto" = the library's choice (64-row LDS tiles below ~48k rows),
-    "rows32" = the wave-per-32-rows forward and the two-kernel backward (tower2.hip) forced at any size."""
+    """Every tower-kernel family on every shape: "auto" = the library's choice (64-row LDS tiles below ~48k rows),
+    "rows32" = the wave-per-32-rows forward and the two-kernel backward (tower2.hip) forced at any size, "coop" = the
+    same forward with the one-kernel backward (tower3.hip: data + weight gradients per tile, d = hidden = 128; other
+    shapes fall back to the library's choice)."""
     if request.param == "rows32":
         monkeypatch.setenv("RIHIP_TOWER_FWD", "3")
         monkeypatch.setenv("RIHIP_TOWER_BWD", "3")   # two-kernel backward (d = hidden = 128), any size
+    elif request.param == "coop":
+        monkeypatch.setenv("RIHIP_TOWER_FWD", "3")
+        monkeypatch.setenv("RIHIP_TOWER_BWD", "4")   # one-kernel backward (d = hidden = 128), any size
     else:
         monkeypatch.delenv("RIHIP_TOWER_FWD", raising=False)
         monkeypatch.delenv("RIHIP_TOWER_BWD", raising=False)
@@ -644,3 +649,41 @@ def test_reduce_and_scatter_in_one_launch_is_bitwise_the_two_calls(B):
     L.check(lib.rihip_backward_reduce2_scatter2(*red_args(g2), *scat_args(t2), st), "fused")
     for a_, b_ in zip(g1[0] + g1[1] + t1, g2[0] + g2[1] + t2):
         assert torch.equal(a_, b_)
+
+
+@pytest.mark.parametrize("item", [False, True])
+@pytest.mark.parametrize("B", [50000, 65536 + 17, 31, 8192])
+def test_one_kernel_backward_equals_the_two_kernel_form(B, item, monkeypatch):
+    """tower3.hip (data + weight gradients of a tile in one kernel, no gy / dPre round trip) against tower2.hip's two
+    kernels on the same inputs: dX and the four weight gradients agree to float-summation-order level; ragged B, a batch
+    smaller than one tile, duplicate ids, dropout scale, rows whose normalisation clamped"""
+    import ctypes as C
+    from recommendit_amd import _lib as L
+    lib, dev = L.lib(), L.device()
+    d = H = 128
+    g = torch.Generator(device=dev); g.manual_seed(B + int(item))
+    n_rows = 4000
+    f32 = dict(dtype=torch.float32, device=dev)
+    K1 = d + (18 if item else 0)
+    t_ = dict(table=torch.randn((n_rows, d), generator=g, **f32), ids=torch.randint(1, n_rows, (B,), device=dev, generator=g),
+              genres=(torch.rand((B, 18), device=dev, generator=g) < 0.2).float() if item else None,
+              W1=torch.randn((H, K1), generator=g, **f32) * 0.1, W2=torch.randn((d, H), generator=g, **f32) * 0.1,
+              gout=torch.randn((B, d), generator=g, **f32), out=torch.randn((B, d), generator=g, **f32),
+              den=torch.rand((B,), generator=g, **f32) + 0.5, hid=torch.relu(torch.randn((B, H), generator=g, **f32)))
+    t_["den"][::97] = 1e-12                                       # the clamp branch of F.normalize
+    res = {}
+    for which in ("3", "4"):
+        monkeypatch.setenv("RIHIP_TOWER_BWD", which)
+        ws = torch.empty((lib.rihip_tower_backward_workspace_floats(B, d, H, int(item)),), **f32)
+        gr = [torch.empty((H, K1), **f32), torch.empty((H,), **f32), torch.empty((d, H), **f32), torch.empty((d,), **f32)]
+        dX = torch.full((B, d), 7.0, **f32)
+        L.check(lib.rihip_tower_backward(t_["table"].data_ptr(), n_rows, t_["ids"].data_ptr(), L.ptr(t_["genres"]), B, d, H,
+                                         t_["W1"].data_ptr(), t_["W2"].data_ptr(), t_["gout"].data_ptr(), t_["out"].data_ptr(),
+                                         t_["den"].data_ptr(), t_["hid"].data_ptr(), 1.25, dX.data_ptr(),
+                                         *(x.data_ptr() for x in gr), 0, ws.data_ptr(), L.stream_ptr()), "bwd")
+        torch.cuda.synchronize()
+        res[which] = [dX] + gr
+    for name, a_, b_ in zip(("dX", "dW1", "db1", "dW2", "db2"), res["3"], res["4"]):
+        scale = float(a_.abs().max()) + 1e-30
+        assert float((a_ - b_).abs().max()) <= 2e-5 * scale, name
+        assert torch.isfinite(b_).all(), name
