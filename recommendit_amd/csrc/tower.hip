@@ -897,17 +897,18 @@ extern "C" int rihip_tower_backward_partial(const float* table, int64_t n_rows, 
     *n_slabs = nslab;
     return RIHIP_OK;
   }
-  {  // chip-filling batches: the one-kernel backward (tower3.hip: data + weight gradients per tile, no gy / dPre round
-     // trip); RIHIP_TOWER_BWD = 4: that kernel at any size (tests), 3: the two-kernel form (tower2.hip) at any size,
-     // 5: the two-kernel form for chip-filling batches (the round-2 default), 1: the fused 64-row-tile kernel
+  {  // chip-filling batches: the two-kernel backward (tower2.hip).  RIHIP_TOWER_BWD = 3: that form at any size (tests),
+     // 4: the one-kernel form (tower3.hip: data + weight gradients per tile, no gy / dPre round trip through HBM) at any
+     // size -- measured slower on MI355X (457 vs 415 us per 196 608 rows: DESIGN.md §9), kept as a tested variant;
+     // 1: the fused 64-row-tile kernel
     const char* ev = getenv("RIHIP_TOWER_BWD");
     const int which = ev ? atoi(ev) : 2;
     const int64_t nt32 = (B + 31) / 32;
-    if (((which == 2 && B >= 49152) || which == 4) && aligned16(W2) && aligned16(dX)) {
+    if (which == 4 && aligned16(W2) && aligned16(dX)) {
       nslab = rihip_launch_tower_bwd3(d, hidden, item, a, (int)(nt32 < RIHIP_NCU ? nt32 : RIHIP_NCU), st);
       if (nslab > 0 && dx_event) (void)hipEventRecord((hipEvent_t)dx_event, st);
     }
-    if (nslab == 0 && (((which == 2 || which == 5) && B >= 49152) || which == 3) && aligned16(W2) && aligned16(dX))
+    if (nslab == 0 && ((which == 2 && B >= 49152) || which == 3) && aligned16(W2) && aligned16(dX))
       nslab = rihip_launch_tower_bwd2(d, hidden, item, a, act, st, (hipEvent_t)dx_event);
   }
   if (nslab == 0) {

@@ -1,6 +1,12 @@
 // Tower backward in ONE kernel (d = hidden = 128, chip-filling batches): data gradients AND weight gradients of a 32-row
 // tile by one 8-wave workgroup, without the row-major gy / dPre round trip through HBM of the two-kernel form
 // (tower2.hip: tower_bwd_data_kernel + tower_wgrad_kernel move ~5 KB per row; this kernel ~2.7 KB).
+// STATUS: correct (tests/test_gpu_towers.py, "coop" kernel family) and selectable with RIHIP_TOWER_BWD=4, but NOT the
+// default: on MI355X it takes 154 + 312 us for 65 536 + 131 072 rows against 138 + 277 us of the two-kernel form.  The
+// LDS holds both weight matrices, so the workgroup is 8 waves = 2 per SIMD = 256 registers per lane; the weight-gradient
+// accumulators (80) + the operands staged for them (96) + gy in the row layout (128 while it is formed) leave no room to
+// request a tile's operands one phase ahead -- a software-pipelined variant spilled 250 B per lane and ran at 405 us --
+// and without that three memory latencies per tile are exposed (15-19 us per tile against 3.8 us of MFMA work).
 // Reference: the implicit autograd backward of UserTower / ItemTower (src/models/two_tower.py:39-42, :68-72; called at
 // src/training/train_embeddings.py:190).
 //
@@ -120,6 +126,7 @@ __global__ __launch_bounds__(512, 2) void tower_bwd3_kernel(TowerBwdArgs a) {
     __syncthreads();     // (B) Ps and the row scalars of this tile are visible
     if (front) {
       // ---- dW1[tile tw, :] += dPre^T . x   (A = dacc: lane = hidden unit, register = batch row; B = x[row][k1])
+      // every x value of the tile is requested before the first MFMA: one memory latency per tile, not one per k1 tile
       int64_t idv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -128,27 +135,30 @@ __global__ __launch_bounds__(512, 2) void tower_bwd3_kernel(TowerBwdArgs a) {
         if (id < 0 || id >= a.n_rows) id = 0;
         idv[r] = id;
       }
+      float xv[NX][16];
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        float xv[16];
+      for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) xv[r] = a.table[idv[r] * D + nt * 32 + r31];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) wacc[nt] = mfma32(dacc[r], xv[r], wacc[nt]);   // (dacc = 0 for rows past B)
-      }
+        for (int r = 0; r < 16; ++r) xv[nt][r] = a.table[idv[r] * D + nt * 32 + r31];
       if (ITEM) {
-        float xv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int64_t rr = row_base + acc_row(r, lane);
-          xv[r] = a.genres[(rr < a.B ? rr : a.B - 1) * 18 + (r31 < 18 ? r31 : 0)];
+          xv[NX - 1][r] = a.genres[(rr < a.B ? rr : a.B - 1) * 18 + (r31 < 18 ? r31 : 0)];
         }
+      }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) wacc[4] = mfma32(dacc[r], r31 < 18 ? xv[r] : 0.f, wacc[4]);
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wacc[nt] = mfma32(dacc[r], xv[nt][r], wacc[nt]);   // (dacc = 0 for rows past B)
+      if (ITEM) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wacc[4] = mfma32(dacc[r], r31 < 18 ? xv[NX - 1][r] : 0.f, wacc[4]);
       }
     } else {
-      // ---- gy of the tile in the feature-per-lane layout for this wave's d tile
-      float gyf[16];
+      // ---- gy of the tile in the feature-per-lane layout for this wave's d tile; all of the tile's loads (gout, out and
+      // the four hidden tiles of hid) are requested before anything consumes them
+      float gyf[16], hv[4][16];
       {
         float gv[16], ov[16];
 #pragma unroll
@@ -157,6 +167,8 @@ __global__ __launch_bounds__(512, 2) void tower_bwd3_kernel(TowerBwdArgs a) {
           const int64_t rc = rr < a.B ? rr : a.B - 1;
           gv[r] = a.gout[rc * D + tw * 32 + r31];
           ov[r] = a.out[rc * D + tw * 32 + r31];
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) hv[nt][r] = a.hid[rc * H + nt * 32 + r31];
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -167,16 +179,9 @@ __global__ __launch_bounds__(512, 2) void tower_bwd3_kernel(TowerBwdArgs a) {
       }
       // ---- dW2[tile tw, :] += gy^T . hid
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        float hv[16];
+      for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t rr = row_base + acc_row(r, lane);
-          hv[r] = a.hid[(rr < a.B ? rr : a.B - 1) * H + nt * 32 + r31];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) wacc[nt] = mfma32(gyf[r], hv[r], wacc[nt]);
-      }
+        for (int r = 0; r < 16; ++r) wacc[nt] = mfma32(gyf[r], hv[nt][r], wacc[nt]);
       // ---- dX[:, tile tw] = dPre . W1[:, tile]   (A = the dPre tile in LDS, B = W1s[h][d])
       f32x16 xacc = zero16();
       const float* w1p = W1s + tw * 32 + r31;

@@ -1,0 +1,16 @@
+#!/bin/bash
+# sampled-negative step (B = 65 536, d = hidden = 128): one-kernel tower backward (tower3.hip, default) vs the two-kernel
+# form (tower2.hip, RIHIP_TOWER_BWD=5), and the per-kernel summary of the default.  Run on the GPU box from the repo root.
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/prof_bwd3
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+python3 $R/tools/sampled_step_bench.py 65536 2>&1 | tail -1
+RIHIP_TOWER_BWD=5 python3 $R/tools/sampled_step_bench.py 65536 2>&1 | tail -1
+rocprofv3 --kernel-trace --stats -d $O -o b --output-format csv -- python3 $R/tools/sampled_step_bench.py 65536 > /dev/null 2>&1
+python3 - <<EOF
+import csv, glob
+f = glob.glob("$O/**/b_kernel_stats.csv", recursive=True)[0]
+for r in list(csv.DictReader(open(f)))[:16]:
+    print(f'{r["Name"][:72]:72s} {r["Calls"]:>5s} {float(r["AverageNs"]) / 1e3:9.1f} us {r["Percentage"]:>6s} %')
+EOF
