@@ -1,6 +1,8 @@
 #!/bin/bash
-# sampled-negative step (B = 65 536, d = hidden = 128): one-kernel tower backward (tower3.hip, default) vs the two-kernel
-# form (tower2.hip, RIHIP_TOWER_BWD=5), and the per-kernel summary of the default.  Run on the GPU box from the repo root.
+# sampled-negative step (B = 65 536, d = hidden = 128) with the three tower-backward forms: line 1 = the default (two
+# kernels, tower2.hip), line 2 = RIHIP_TOWER_BWD=5 (neither chip-filling form: the fused 64-row-tile kernel of tower.hip),
+# then the per-kernel summary of the default; append `RIHIP_TOWER_BWD=4 python3 tools/sampled_step_bench.py 65536` for
+# the one-kernel form (tower3.hip).  Run on the GPU box from the repo root.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof_bwd3
 mkdir -p $O

@@ -7,7 +7,7 @@
 # Every rocprofv3 line runs the python program directly (no env/bash hop).  The counter passes use --kernel-trace --pmc
 # (kernel dispatch records are what carries the counters) and never add -s/-r or the hip/hsa/memory-copy/marker domains.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 PART=${2:-all}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof_$TAG
