@@ -620,6 +620,15 @@ struct FinArgs {
   int sort_slots;         // uint64 slots of the sort buffer in front of them
 };
 
+#ifdef RIHIP_FIN_PROBE
+__device__ unsigned long long g_fin_probe[16];
+#define FIN_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_fin_probe[k] = wall_clock64(); } while (0)
+extern "C" int rihip_debug_fin_probe(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fin_probe), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : 1;
+}
+#else
+#define FIN_STAMP(k)
+#endif
 // radix passes + compaction of finalize_kernel over the key list `kp` (the query's slice of the global candidate list, or
 // its copy in LDS: the address space is inferred after inlining, so the LDS call compiles to ds_* instructions)
 __device__ __forceinline__ uint64_t finalize_select(const FinArgs& a, const uint64_t* kp, const int64_t n, const int k_sel,
@@ -680,6 +689,7 @@ __device__ __forceinline__ uint64_t finalize_select(const FinArgs& a, const uint
       // #{key >= T} == k_sel
       const bool done = (hist[s_bin] == need);
       __syncthreads();
+      FIN_STAMP(4 + pass);
       if (done) break;
     }
     T = prefix;
@@ -725,10 +735,18 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
   // Small launches (single requests: a handful of workgroups, each a chain of up to 8 dependent passes over its list)
   // copy the list into LDS once and select there: 48 -> 2x us for the 12k-slot lists of one request's probes.
   uint64_t T;
+  FIN_STAMP(0);
   if (a.lds_keys > 0 && n <= a.lds_keys) {
     uint64_t* kS = sbuf + a.sort_slots;
-    for (int64_t i = tid; i < n; i += 256) kS[i] = keys[i];
+    for (int64_t i0 = tid; i0 < n; i0 += 256 * 8) {     // 8 independent loads in flight per thread
+      uint64_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int64_t i = i0 + u * 256; v[u] = keys[i < n ? i : n - 1]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int64_t i = i0 + u * 256; if (i < n) kS[i] = v[u]; }
+    }
     __syncthreads();
+    FIN_STAMP(1);
     T = finalize_select(a, kS, n, k_sel, hist, s_bin, s_above, s_cnt, sbuf, P);
   } else {
     T = finalize_select(a, keys, n, k_sel, hist, s_bin, s_above, s_cnt, sbuf, P);
@@ -738,12 +756,16 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
     if (tid == 0) a.thr_out[q] = (k_sel > 0 && k_sel == a.rank) ? ord2f((uint32_t)(T >> 32)) : -INFINITY;
     return;
   }
+  FIN_STAMP(2);
   {  // keys are unique except the all-zero padding key: the remaining slots all equal T
     const int cgt = (int)s_cnt;
     for (int i = cgt + tid; i < k_sel; i += 256) sbuf[i] = T;
   }
   __syncthreads();
-  for (int size = 2; size <= P; size <<= 1) {
+  // (the hierarchical select's first level hands its k keys to a second finalize, which sorts: no sort here -- 45
+  // barrier-separated stages, 12 us, for nothing)
+  const bool need_sort = a.out_keys == nullptr || a.thr_chk != nullptr;
+  for (int size = 2; need_sort && size <= P; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
       for (int i = tid; i < P / 2; i += 256) {
         const int lo = (i / stride) * (stride << 1) + (i % stride);
@@ -755,6 +777,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
       __syncthreads();
     }
   }
+  FIN_STAMP(3);
   if (a.thr_chk && k_sel == a.k && k_sel > 0) {  // completeness proof of the approximate filter
     const float sk = ord2f((uint32_t)(sbuf[k_sel - 1] >> 32));
     if (sk < a.thr_chk[q] + a.eps_scale * a.qnorm[q] + 2e-6f) fail = true;

@@ -23,3 +23,12 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "eager"
 for i in range(30):
     pipe.recommend_batch([1 + i], graph=(mode == "graph"))
 torch.cuda.synchronize()
+if os.environ.get("RIHIP_FIN_PROBE"):
+    import ctypes as C
+    from recommendit_amd import _lib as L
+    buf = (C.c_ulonglong * 16)()
+    fn = L.lib().rihip_debug_fin_probe
+    fn.argtypes = [C.c_void_p]
+    fn(buf)
+    v = list(buf)
+    print("finalize (last launch, workgroup 0) stamps, us since start:", [round((x - v[0]) / 100.0, 1) if x >= v[0] else None for x in v[:12]])
