@@ -20,8 +20,9 @@ store = GpuFeatureStore(8, 8)
 store._dev = (torch.rand((nu + 1, 24), device=dev, generator=g, dtype=torch.float64), torch.rand((N + 1, 23), device=dev, generator=g, dtype=torch.float64))
 pipe = GpuRecommendationPipeline(model, ivf, ranker, store, top_k_candidates=500, top_k_results=20)
 mode = sys.argv[1] if len(sys.argv) > 1 else "eager"
+nb = int(sys.argv[2]) if len(sys.argv) > 2 else 1       # requests per batch
 for i in range(30):
-    pipe.recommend_batch([1 + i], graph=(mode == "graph"))
+    pipe.recommend_batch([1 + (i * nb + j) % nu for j in range(nb)], graph=(mode == "graph"))
 torch.cuda.synchronize()
 if os.environ.get("RIHIP_FIN_PROBE"):
     import ctypes as C

@@ -2,10 +2,11 @@
 # last single request of tools/single_request_trace.py: kernel, duration, gap to the previous kernel (us)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 MODE=${1:-eager}
+NB=${2:-1}
 O=$R/gpurun_out/prof_single_$MODE
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace -d $O -o s --output-format csv -- python3 $R/tools/single_request_trace.py $MODE > /dev/null 2>&1
+rocprofv3 --kernel-trace -d $O -o s --output-format csv -- python3 $R/tools/single_request_trace.py $MODE $NB > /dev/null 2>&1
 python3 - <<EOF
 import csv, glob
 f = glob.glob("$O/**/s_kernel_trace.csv", recursive=True)[0]
