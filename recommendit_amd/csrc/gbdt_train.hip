@@ -53,7 +53,8 @@ namespace {
 
 constexpr int NBIN = 256;
 constexpr int HCH = 1024;        // rows per histogram workgroup: 1024 x 2^20 < 2^31 keeps int32 sums exact
-constexpr int FCH = 32;          // features per histogram pass (32 x 256 x 3 x 4 B = 96 KB of LDS; 16 with 8-byte cells)
+constexpr int FCH = 50;          // features per histogram pass (50 x 256 x 3 x 4 B = 150 KB of LDS; 25 with 8-byte cells):
+                                 // the reference's 50 ranking features in ONE pass over the rows
 constexpr int MAX_GROUP = 16384; // documents per query (sorted scores + labels of a query live in LDS)
 constexpr int MAX_T = 32;        // truncation level supported by the per-thread pair accumulators
 constexpr double QLEVELS = 1048576.0;
@@ -239,10 +240,6 @@ __global__ __launch_bounds__(256) void hist_kernel(const uint8_t* __restrict__ X
     if (v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(hist) + (size_t)f0 * NBIN * 3 + i, (unsigned long long)(long long)v);
   }
 }
-__global__ void hist_sub_kernel(const long long* __restrict__ parent, const long long* __restrict__ small, long long* big, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) big[i] = parent[i] - small[i];
-}
 
 __device__ __forceinline__ double thr_l1(double g, double l1) {
   const double t = fabs(g) - l1;
@@ -264,13 +261,21 @@ __device__ __forceinline__ double leaf_gain(double G, double H, double l1, doubl
 __global__ __launch_bounds__(1024) void split_kernel(const long long* __restrict__ hist0, const long long* __restrict__ hist1,
                                                      int F, const int* __restrict__ nb, const int* __restrict__ nanbin,
                                                      const unsigned char* __restrict__ used, double sg, double sh, double l1,
-                                                     double l2, int min_child, double min_hess, int order, SplitInfo* out0) {
+                                                     double l2, int min_child, double min_hess, int order, SplitInfo* out0,
+                                                     const long long* __restrict__ sub_small, int sub_child) {
   constexpr int NWV = 16;
   __shared__ SplitInfo best_w[NWV];
-  const long long* __restrict__ hist = blockIdx.x == 0 ? hist0 : hist1;
+  const long long* hist = blockIdx.x == 0 ? hist0 : hist1;
   SplitInfo* out = out0 + blockIdx.x;
   if (!hist) return;   // this child is not split further
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (sub_small && (int)blockIdx.x == sub_child) {
+    // the larger child of a split: its histogram is parent - smaller child, formed here, in place in the parent's slot
+    // (what was a launch of its own); the workgroup then reads what it wrote
+    long long* hw = const_cast<long long*>(hist);
+    for (int i = tid; i < F * NBIN * 3; i += 1024) hw[i] -= sub_small[i];
+    __syncthreads();
+  }
   SplitInfo best; best.gain = 0.0; best.feature = -1; best.bin = 0; best.glq = best.hlq = best.cl = 0; best.gq = best.hq = best.c = 0;
   best.default_left = 1; best.pad = 0;
   for (int f = w; f < F; f += NWV) {
@@ -351,26 +356,60 @@ __global__ __launch_bounds__(1024) void split_kernel(const long long* __restrict
   }
 }
 
-// left = bin <= threshold bin; the rows of the feature's missing bin follow the node's default direction
-__global__ void part_flags_kernel(const uint8_t* __restrict__ Xb, int F, const int* __restrict__ rows, int64_t b0, int64_t len,
-                                  int f, int bin, int nanbin, int default_left, int* flags) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < len) {
-    const int x = Xb[(size_t)rows[b0 + i] * F + f];
-    flags[i] = (x == nanbin) ? default_left : (x <= bin ? 1 : 0);
+// Partition of a leaf's rows in ONE launch: left = bin <= threshold bin, the rows of the feature's missing bin follow the
+// node's default direction.  Every workgroup takes 8192 rows, counts its left / right rows (wave scans + 16 wave totals),
+// reserves its two output ranges with one atomic each on the split's cursor pair, and writes src -> dst (the two row
+// buffers alternate from parent to children: no copy back).  The order of the rows INSIDE a child depends on the order
+// the workgroups arrive -- nothing downstream depends on it: histograms and leaf sums are integer sums.  (It replaced
+// flags + a two-kernel rocPRIM scan + scatter + copy: five launches per split.)
+constexpr int PART_ROWS = 8192;
+__global__ __launch_bounds__(1024) void part_kernel(const uint8_t* __restrict__ Xb, int F, const int* __restrict__ src,
+                                                    int* __restrict__ dst, int64_t b0, int64_t len, int f, int bin, int nanbin,
+                                                    int default_left, int* cursors, int64_t n_left) {
+  __shared__ int wl[16], wr[16];
+  __shared__ int baseL, baseR;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t c0 = (int64_t)blockIdx.x * PART_ROWS;
+  int row[8];
+  bool lft[8], ok[8];
+  int nl = 0, nr = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int64_t i = c0 + (int64_t)k * 1024 + tid;
+    ok[k] = i < len;
+    row[k] = src[b0 + (ok[k] ? i : len - 1)];
   }
-}
-__global__ void part_scatter_kernel(const int* __restrict__ rows, int64_t b0, int64_t len, const int* __restrict__ flags,
-                                    const int* __restrict__ scan, int64_t n_left, int* out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= len) return;
-  const int r = rows[b0 + i];
-  if (flags[i]) out[b0 + scan[i]] = r;               // exclusive scan of the flags: stable on both sides
-  else out[b0 + n_left + (i - scan[i])] = r;
-}
-__global__ void copy_int_kernel(const int* __restrict__ src, int* dst, int64_t b0, int64_t len) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < len) dst[b0 + i] = src[b0 + i];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int x = Xb[(size_t)row[k] * F + f];
+    lft[k] = (x == nanbin) ? (default_left != 0) : (x <= bin);
+    nl += (ok[k] && lft[k]) ? 1 : 0;
+    nr += (ok[k] && !lft[k]) ? 1 : 0;
+  }
+  int il = nl, ir = nr;                       // inclusive scans over the wave
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int tl = __shfl_up(il, o, 64), tr = __shfl_up(ir, o, 64);
+    if (lane >= o) { il += tl; ir += tr; }
+  }
+  if (lane == 63) { wl[w] = il; wr[w] = ir; }
+  __syncthreads();
+  int offL = il - nl, offR = ir - nr;
+  for (int k = 0; k < w; ++k) { offL += wl[k]; offR += wr[k]; }
+  if (tid == 0) {
+    int TL = 0, TR = 0;
+    for (int k = 0; k < 16; ++k) { TL += wl[k]; TR += wr[k]; }
+    baseL = TL ? atomicAdd(&cursors[0], TL) : 0;
+    baseR = TR ? atomicAdd(&cursors[1], TR) : 0;
+  }
+  __syncthreads();
+  int* dl = dst + b0 + baseL + offL;
+  int* dr = dst + b0 + n_left + baseR + offR;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (!ok[k]) continue;
+    if (lft[k]) *dl++ = row[k]; else *dr++ = row[k];
+  }
 }
 template <typename T>
 __global__ void sum_leaf_kernel(const int* __restrict__ rows, int64_t b0, int64_t len, const T* __restrict__ gq,
@@ -640,23 +679,21 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
   const size_t HSZ = (size_t)F * NBIN * 3;
   double *ls = nullptr, *hs = nullptr, *lam = nullptr, *hes = nullptr, *d_leafv = nullptr;
   void *gq = nullptr, *hq = nullptr;      // int32 (2^20 levels) or int64 (up to 2^40 levels) per row
-  int *rowsA = nullptr, *rowsB = nullptr, *flags = nullptr, *scan = nullptr;
+  int *rowsA = nullptr, *rowsB = nullptr, *d_cur = nullptr;
   int *d_feat = nullptr, *d_bin = nullptr, *d_lc = nullptr, *d_rc = nullptr;
   long long* hist = nullptr; long long* d_sum = nullptr; unsigned long long* d_mx = nullptr; unsigned char* d_used = nullptr;
-  SplitInfo* d_split = nullptr; void* scan_tmp = nullptr; size_t scan_bytes = 0;
+  SplitInfo* d_split = nullptr;
   hipMalloc((void**)&ls, sizeof(double) * n); hipMalloc((void**)&hs, sizeof(double) * n);
   hipMalloc((void**)&lam, sizeof(double) * n); hipMalloc((void**)&hes, sizeof(double) * n);
   hipMalloc(&gq, (wide ? 8 : 4) * (size_t)n); hipMalloc(&hq, (wide ? 8 : 4) * (size_t)n);
   hipMalloc((void**)&rowsA, sizeof(int) * n); hipMalloc((void**)&rowsB, sizeof(int) * n);
-  hipMalloc((void**)&flags, sizeof(int) * n); hipMalloc((void**)&scan, sizeof(int) * n);
+  hipMalloc((void**)&d_cur, sizeof(int) * 2 * 128);      // a cursor pair per split of a tree (num_leaves <= 128)
   hipMalloc((void**)&hist, sizeof(long long) * HSZ * (size_t)NL); hipMalloc((void**)&d_sum, sizeof(long long) * 2);
   hipMalloc((void**)&d_mx, sizeof(unsigned long long) * 2); hipMalloc((void**)&d_used, F);
   hipMalloc((void**)&d_split, sizeof(SplitInfo) * 2);
   hipMalloc((void**)&d_feat, sizeof(int) * NL); hipMalloc((void**)&d_bin, sizeof(int) * NL);
   hipMalloc((void**)&d_lc, sizeof(int) * NL); hipMalloc((void**)&d_rc, sizeof(int) * NL); hipMalloc((void**)&d_leafv, sizeof(double) * NL);
-  (void)rocprim::exclusive_scan(nullptr, scan_bytes, flags, scan, 0, (size_t)n, rocprim::plus<int>(), st);
-  hipMalloc(&scan_tmp, scan_bytes ? scan_bytes : 16);
-  if (hipGetLastError() != hipSuccess || !scan_tmp || !d_leafv) { rihip_set_error("lambdamart_train: device allocation failed"); return RIHIP_ERR_HIP; }
+  if (hipGetLastError() != hipSuccess || !d_cur || !d_leafv) { rihip_set_error("lambdamart_train: device allocation failed"); return RIHIP_ERR_HIP; }
   const size_t grad_lds = [&] { int mg = 1; for (int q = 0; q < ng; ++q) mg = std::max(mg, (int)groups[q]); return (size_t)mg * 9 + 64; }();
   static bool granted = false;
   if (!granted) {
@@ -670,7 +707,7 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
     TCHK(hipMemsetAsync(dst, 0, sizeof(long long) * HSZ, st));
     if (len <= 0) return RIHIP_OK;
     const unsigned nchunk = (unsigned)((len + HCH - 1) / HCH);
-    const int fch = wide ? FCH / 2 : FCH;     // the same 96 KB of LDS with 8-byte cells
+    const int fch = wide ? FCH / 2 : FCH;     // the same 150 KB of LDS with 8-byte cells
     for (int f0 = 0; f0 < F; f0 += fch) {
       const int nf = std::min(fch, F - f0);
       if (wide)
@@ -687,7 +724,7 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
   // best splits of up to two leaves (the children of a split) in one launch; a null histogram = leaf not tried
   auto find_splits = [&](const long long* h0, const long long* h1, SplitInfo* slots) {
     hipLaunchKernelGGL(split_kernel, dim3(h1 ? 2 : 1), dim3(1024), 0, st, h0, h1, F, d_nb, d_nanbin, d_used, sg, sh, p->reg_alpha,
-                       p->reg_lambda, p->min_child_samples, p->min_sum_hessian, split_order, slots);
+                       p->reg_lambda, p->min_child_samples, p->min_sum_hessian, split_order, slots, (const long long*)nullptr, -1);
   };
   SplitInfo* h_split = nullptr;   // pinned: the per-split read-back is on the critical path of the tree growth
   if (hipHostMalloc((void**)&h_split, sizeof(SplitInfo) * 2) != hipSuccess) h_split = nullptr;
@@ -747,7 +784,9 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
       hipStreamSynchronize(st);
     }
     // ---- grow the tree (best-first): leaf l owns rows[b .. b+len)
-    struct Leaf { int64_t b, len; int parent_node, side, slot; SplitInfo s; bool has; long long gq, hq, c; };
+    struct Leaf { int64_t b, len; int parent_node, side, slot, buf; SplitInfo s; bool has; long long gq, hq, c; };
+    int* rowsBuf[2] = {rowsA, rowsB};    // a leaf's rows live in rowsBuf[leaf.buf]; children get the other buffer
+    hipMemsetAsync(d_cur, 0, sizeof(int) * 2 * 128, st);
     std::vector<Leaf> leaves;
     Tree tree;
     hipLaunchKernelGGL(iota_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rowsA, n);
@@ -760,7 +799,7 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
       return RIHIP_OK;
     };
     {
-      Leaf root; root.b = 0; root.len = n; root.parent_node = -1; root.side = 0; root.slot = 0; root.has = false;
+      Leaf root; root.b = 0; root.len = n; root.parent_node = -1; root.side = 0; root.slot = 0; root.buf = 0; root.has = false;
       rc = build_hist(rowsA, 0, n, hist);
       if (rc) break;
       find_splits(hist, nullptr, d_split);
@@ -809,28 +848,22 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
         tree.int_w.push_back(H);
       }
       if (par.parent_node >= 0) (par.side == 0 ? tree.lc : tree.rc)[par.parent_node] = node;
-      // partition the rows of the leaf (stable): left = bin <= threshold bin
-      {
-        const unsigned g = (unsigned)((par.len + 255) / 256);
-        hipLaunchKernelGGL(part_flags_kernel, dim3(g), dim3(256), 0, st, T.Xb, F, rowsA, par.b, par.len, sp.feature, sp.bin, f_nan, sp.default_left, flags);
-        size_t tb = scan_bytes;
-        if (rocprim::exclusive_scan(scan_tmp, tb, flags, scan, 0, (size_t)par.len, rocprim::plus<int>(), st) != hipSuccess) { rihip_set_error("lambdamart_train: scan failed"); rc = RIHIP_ERR_HIP; break; }
-        hipLaunchKernelGGL(part_scatter_kernel, dim3(g), dim3(256), 0, st, rowsA, par.b, par.len, flags, scan, (int64_t)sp.cl, rowsB);
-        hipLaunchKernelGGL(copy_int_kernel, dim3(g), dim3(256), 0, st, rowsB, rowsA, par.b, par.len);
-      }
+      // partition the rows of the leaf into the other row buffer: left = bin <= threshold bin (one launch)
+      hipLaunchKernelGGL(part_kernel, dim3((unsigned)((par.len + PART_ROWS - 1) / PART_ROWS)), dim3(1024), 0, st, T.Xb, F,
+                         rowsBuf[par.buf], rowsBuf[1 - par.buf], par.b, par.len, sp.feature, sp.bin, f_nan, sp.default_left,
+                         d_cur + 2 * node, (int64_t)sp.cl);
       Leaf L = par, R = par;
       L.len = sp.cl; R.b = par.b + sp.cl; R.len = par.len - sp.cl;
       L.parent_node = node; L.side = 0; R.parent_node = node; R.side = 1;
+      L.buf = R.buf = 1 - par.buf;
       L.gq = sp.glq; L.hq = sp.hlq; L.c = sp.cl; R.gq = sp.gq - sp.glq; R.hq = sp.hq - sp.hlq; R.c = sp.c - sp.cl;
       // histograms: the smaller child is built, the larger one is parent - smaller (kept in the parent's slot)
       const bool left_small = L.len <= R.len;
       Leaf& S = left_small ? L : R;
       Leaf& Bg = left_small ? R : L;
       S.slot = n_slots++; Bg.slot = par.slot;
-      rc = build_hist(rowsA, S.b, S.len, hist + (size_t)S.slot * HSZ);
+      rc = build_hist(rowsBuf[S.buf], S.b, S.len, hist + (size_t)S.slot * HSZ);
       if (rc) break;
-      hipLaunchKernelGGL(hist_sub_kernel, dim3((unsigned)((HSZ + 255) / 256)), dim3(256), 0, st, hist + (size_t)par.slot * HSZ,
-                         hist + (size_t)S.slot * HSZ, hist + (size_t)Bg.slot * HSZ, (int)HSZ);
       const bool tryL = L.len >= 2 * (int64_t)p->min_child_samples, tryR = R.len >= 2 * (int64_t)p->min_child_samples;
       SplitInfo two[2];
       memset(two, 0, sizeof(two));
@@ -839,9 +872,12 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
         // (grid of 2 whenever the right child is tried: a null left histogram makes workgroup 0 return at once)
         const long long* hL = tryL ? hist + (size_t)L.slot * HSZ : nullptr;
         const long long* hR = tryR ? hist + (size_t)R.slot * HSZ : nullptr;
-        if (tryR) hipLaunchKernelGGL(split_kernel, dim3(2), dim3(1024), 0, st, hL, hR, F, d_nb, d_nanbin, d_used, sg, sh, p->reg_alpha,
-                                     p->reg_lambda, p->min_child_samples, p->min_sum_hessian, split_order, d_split);
-        else find_splits(hL, nullptr, d_split);
+        // the larger child's histogram = parent - smaller child is formed by its own split workgroup (in place, in the
+        // parent's slot); a larger child that is not tried is a final leaf: its histogram is never read again
+        const long long* hS = hist + (size_t)S.slot * HSZ;
+        const int big_child = left_small ? 1 : 0;
+        hipLaunchKernelGGL(split_kernel, dim3(tryR ? 2 : 1), dim3(1024), 0, st, hL, hR, F, d_nb, d_nanbin, d_used, sg, sh, p->reg_alpha,
+                           p->reg_lambda, p->min_child_samples, p->min_sum_hessian, split_order, d_split, hS, big_child);
         rc = read_splits(two, 2);
         if (rc) break;
       }
@@ -861,7 +897,7 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
       tree.leaf[l] = -thr1 / (H + p->reg_lambda) * p->learning_rate;
       tree.leaf_w[l] = H; tree.leaf_cnt[l] = leaves[l].c;
       if (leaves[l].len > 0)
-        hipLaunchKernelGGL(add_leaf_kernel, dim3((unsigned)((leaves[l].len + 255) / 256)), dim3(256), 0, st, rowsA, leaves[l].b,
+        hipLaunchKernelGGL(add_leaf_kernel, dim3((unsigned)((leaves[l].len + 255) / 256)), dim3(256), 0, st, rowsBuf[leaves[l].buf], leaves[l].b,
                            leaves[l].len, tree.leaf[l], T.score);
     }
     if (has_valid) {
@@ -881,8 +917,8 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
     trees.push_back(std::move(tree));
   }
   hipStreamSynchronize(st);
-  hipFree(ls); hipFree(hs); hipFree(lam); hipFree(hes); hipFree(gq); hipFree(hq); hipFree(rowsA); hipFree(rowsB); hipFree(flags);
-  hipFree(scan); hipFree(hist); hipFree(d_sum); hipFree(d_mx); hipFree(d_used); hipFree(d_split); hipFree(scan_tmp);
+  hipFree(ls); hipFree(hs); hipFree(lam); hipFree(hes); hipFree(gq); hipFree(hq); hipFree(rowsA); hipFree(rowsB); hipFree(d_cur);
+  hipFree(hist); hipFree(d_sum); hipFree(d_mx); hipFree(d_used); hipFree(d_split);
   if (h_split) hipHostFree(h_split);
   hipFree(d_feat); hipFree(d_bin); hipFree(d_lc); hipFree(d_rc); hipFree(d_leafv);
   T.release(); V.release(); hipFree(d_ub); hipFree(d_nb); hipFree(d_nanbin); hipFree(d_gain); hipFree(d_ks);
