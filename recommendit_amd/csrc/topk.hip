@@ -215,30 +215,19 @@ __global__ __launch_bounds__(256) void rownorm_max_kernel(const float* __restric
   if (lane == 0) atomicMax(out_bits, __float_as_int(best));
 }
 
+#ifndef RIHIP_SCAN_ABLATE
+#define RIHIP_SCAN_ABLATE 0
+#endif
 constexpr int QBB = 256;  // queries per workgroup of the bf16 filter (64 per wave: two 32-query groups)
 
 constexpr int TRB = 64;     // corpus rows per pipeline stage of the bf16 filter (two 32-row MFMA sub-tiles)
-constexpr int QCOLS = 192;  // survivor queue: 16-score accumulator columns per workgroup (LDS)
+constexpr int WQE = 192;    // survivor queue: 16-byte entries (score, row, query) per WAVE (LDS)
 constexpr int SAMPLE_T = 8;  // threshold sample: scores kept per stream (query, corpus split, row half)
 
 __device__ __forceinline__ float max3_raw(float a, float b, float c) {  // no NaN-canonicalising pre-ops
   float m;
   asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(a), "v"(b), "v"(c));
   return m;
-}
-
-// queue full (dense survivors): append this column's survivors straight to the query's candidate list.  Kept out of
-// line so that its global atomics/stores do not make hipcc drain the prefetch in the hot loop.
-__device__ __noinline__ void scan_slow_append(const float* col16, float th, int64_t v_base, int hh, int64_t n_virtual,
-                                              int* count_q, uint64_t* cand_q, int64_t cap) {
-  for (int r = 0; r < 16; ++r) {
-    const int64_t v = v_base + (r & 3) + 8 * (r >> 2) + 4 * hh;
-    const float sc = col16[r];
-    if (v < n_virtual && sc >= th) {
-      const int pos = atomicAdd(count_q, 1);
-      if (pos < cap) cand_q[pos] = make_key(sc, (uint32_t)v);
-    }
-  }
 }
 
 // DENSE=false: survivors (score >= thr[q]) are queued in LDS and flushed to the per-query candidate lists now and then,
@@ -257,14 +246,14 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void scan_bf16_kernel(ScanA
   constexpr int NV = (TRB * (D / 8) + 255) / 256;  // 16-byte pieces staged per thread per stage
   __shared__ __attribute__((aligned(16))) __bf16 Xs[2][TRB * LDB];
   // A survivor is rare per lane but not per 64-lane wave (a wave meets one in ~90 % of its 16-score columns at k = 500),
-  // so the hot path must neither wait nor synchronise: a lane whose column holds a candidate dumps the whole column
-  // (4 x ds_write_b128 + header) into its WAVE's private queue at a slot computed from a ballot (no LDS atomic, no
-  // returning operation: with a workgroup-wide atomic counter this path cost more than the MFMA work -- 0.9 of
-  // 1.85 ms, measured by switching it off); thresholding per element and the global appends happen in flush().
-  constexpr int WQ = QCOLS / 4;   // columns per wave queue
-  __shared__ __attribute__((aligned(16))) float qsc[DENSE ? 1 : QCOLS][16];
-  __shared__ unsigned qhdr[DENSE ? 1 : QCOLS][2];
-  __shared__ float thrS[DENSE ? 1 : QBB];   // thresholds of the block's queries (read by the flush)
+  // so the hot path must neither wait nor synchronise.  A column whose maximum passes the threshold is scanned score by
+  // score; the lanes holding a survivor write ONE 16-byte entry (score, row, query) each into their WAVE's private queue
+  // at a slot computed from the compare mask (no LDS atomic, no returning operation: with a workgroup-wide atomic
+  // counter this path cost more than the MFMA work).  Until round 3 the whole 16-score column was dumped (4 x
+  // ds_write_b128 + 2 header words per column, thresholded again in the flush): those six LDS instructions per column
+  // loaded the LDS pipe as much as the MFMA operand reads did, and the 72-byte columns filled the queue nine times
+  // sooner.
+  __shared__ __attribute__((aligned(16))) uint4 qent[DENSE ? 1 : 4][DENSE ? 1 : WQE];
   __shared__ int qcntS[DENSE ? 1 : QBB];    // survivors of each query in this corpus split (one writer wave each)
   __shared__ unsigned wcnt[2][4];           // queue lengths published at the stage barrier, double-buffered by parity
   int wpar = 0;
@@ -317,7 +306,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void scan_bf16_kernel(ScanA
     return;
   }
   if (!DENSE) {   // visible to the flush after the first stage barrier
-    if (hh == 0) { thrS[ql0] = ok0 ? th0 : INFINITY; thrS[ql1] = ok1 ? th1 : INFINITY; qcntS[ql0] = 0; qcntS[ql1] = 0; }
+    if (hh == 0) { qcntS[ql0] = 0; qcntS[ql1] = 0; }
   }
 
   // staging: every thread owns the same (row-in-16, 16-byte column) slot of each 16-row slab of a stage, so a full
@@ -376,77 +365,58 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void scan_bf16_kernel(ScanA
       }
       return;
     }
-    // The v_max3 chain is inline asm, which the compiler's MFMA->VALU hazard recognizer does not see: the chain must
-    // not be the first reader of the accumulator (it read stale registers when it directly followed the MFMAs and
-    // lost survivors).  The compiler-visible fmaxf below reads the accumulator first (hipcc pads it with the required
-    // wait states) and seeds the chain, so every asm read is ordered behind it.
-    float mx = fmaxf(acc[14], acc[15]);
-    mx = max3_raw(mx, acc[0], acc[1]);
-    mx = max3_raw(mx, acc[2], acc[3]);
-    mx = max3_raw(mx, acc[4], acc[5]);
-    mx = max3_raw(mx, acc[6], acc[7]);
-    mx = max3_raw(mx, acc[8], acc[9]);
-    mx = max3_raw(mx, acc[10], acc[11]);
-    mx = max3_raw(mx, acc[12], acc[13]);
-    const bool has = ok && mx >= th;
-    const unsigned long long bal = __ballot(has);
-    if (bal == 0ull) return;             // wave-uniform: no survivor in the wave's 64 columns
-    const unsigned pos = wq_cnt + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
-    wq_cnt += (unsigned)__popcll(bal);
-    if (!has) return;
-    if (pos < (unsigned)WQ) {
-      const unsigned slot = (unsigned)w * WQ + pos;
-      f32x4* dst = reinterpret_cast<f32x4*>(qsc[slot]);
-      dst[0] = f32x4{acc[0], acc[1], acc[2], acc[3]};
-      dst[1] = f32x4{acc[4], acc[5], acc[6], acc[7]};
-      dst[2] = f32x4{acc[8], acc[9], acc[10], acc[11]};
-      dst[3] = f32x4{acc[12], acc[13], acc[14], acc[15]};
-      qhdr[slot][0] = (unsigned)ql | ((unsigned)hh << 16);
-      qhdr[slot][1] = (unsigned)v_base;
-    } else {  // queue full: rare slow path, still exact
-      float col[16];
+    // The v_max3 ops are inline asm, which the compiler's MFMA->VALU hazard recognizer does not see: they must not be the
+    // first readers of the accumulator (they read stale registers when they directly followed the MFMAs and lost
+    // survivors).  Every group maximum starts with a compiler-visible fmaxf (hipcc pads it with the required wait
+    // states), so every asm read is ordered behind one.
+    float g[4];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) col[r] = acc[r];
-      scan_slow_append(col, th, v_base, hh, a.n_virtual, &qcntS[ql], a.seg + ((size_t)qrow * a.nsplit + by) * a.seg_cap, a.seg_cap);
-    }
-  };
-  // The wave empties its OWN queue (no barrier, no other wave involved): columns -> per-query candidate lists, 16 lanes
-  // per column, 4 columns per step, 4 steps batched so that their LDS reads, returning atomics (one per column, not
-  // per survivor) and stores are in flight together (done one step at a time the flush was latency-bound and cost as
-  // much as the MFMA work).
-  auto wave_flush = [&]() {
-    const unsigned n = wq_cnt < (unsigned)WQ ? wq_cnt : (unsigned)WQ;   // columns beyond WQ went the slow path
-    const int l15 = lane & 15, g4 = lane >> 4;
-    for (unsigned c0 = 0; c0 < n; c0 += 16) {
-      float sc[4]; int64_t qg[4], v[4]; bool hit[4]; unsigned grp[4]; int base[4];
+    for (int k = 0; k < 4; ++k) g[k] = max3_raw(fmaxf(acc[4 * k], acc[4 * k + 1]), acc[4 * k + 2], acc[4 * k + 3]);
+    const float mx = max3_raw(fmaxf(g[0], g[1]), g[2], g[3]);
+    const float te = ok ? th : INFINITY;
+#if RIHIP_SCAN_ABLATE == 1   // experiments: the filter without survivor handling (scores computed, maxima taken, nothing kept)
+    asm volatile("" :: "v"(mx));
+    return;
+#endif
+    if (__ballot(mx >= te) == 0ull) return;   // wave-uniform: no survivor in the wave's 64 columns (1 in 6 at k = 500)
+    // Survivors are found group of four by group of four, all branches wave-uniform: a wave's 1 024 scores hold ~1.7
+    // survivors, so ~1.4 of the 4 groups and ~1.1 scores of such a group take the queue path.
+    const unsigned vl = (unsigned)v_base + 4u * (unsigned)hh;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (__ballot(g[k] >= te) == 0ull) continue;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const unsigned col = c0 + 4 * j + g4;
-        const bool in = col < n;
-        const unsigned c = (unsigned)w * WQ + (in ? col : 0);
-        const unsigned h0 = qhdr[c][0];
-        const unsigned ql = h0 & 0xFFFFu;
-        qg[j] = qb0 + ql;
-        v[j] = (int64_t)qhdr[c][1] + (l15 & 3) + 8 * (l15 >> 2) + 4 * (h0 >> 16);
-        sc[j] = qsc[c][l15];
-        hit[j] = in && v[j] < a.n_virtual && sc[j] >= thrS[ql];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const unsigned long long bal = __ballot(hit[j]);
-        grp[j] = (unsigned)(bal >> (16 * g4)) & 0xFFFFu;
-        base[j] = 0;
-        if (grp[j] && l15 == __ffs(grp[j]) - 1) base[j] = atomicAdd(&qcntS[qg[j] - qb0], __popc(grp[j]));   // LDS
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int b = __shfl(base[j], (lane & ~15) + (grp[j] ? __ffs(grp[j]) - 1 : 0), 64);
-        if (hit[j]) {
-          const int pos = b + __popc(grp[j] & ((1u << l15) - 1u));
-          if (pos < a.seg_cap) a.seg[((size_t)qg[j] * a.nsplit + by) * a.seg_cap + pos] = make_key(sc[j], (uint32_t)v[j]);
+        const float sc = acc[4 * k + j];
+        const bool h = sc >= te;
+        const unsigned long long m = __ballot(h);
+        if (m == 0ull) continue;
+        const unsigned pos = wq_cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        wq_cnt += (unsigned)__popcll(m);
+        if (h) {
+          if (pos < (unsigned)WQE) qent[w][pos] = uint4{__float_as_uint(sc), vl + (unsigned)(j + 8 * k), (unsigned)ql, 0u};
+          else atomicOr(&qcntS[ql], 1 << 30);   // queue full (a stage brought > 64 survivors to one wave): the segment is
+                                                // marked overflowed and the query takes the exact re-do path
         }
       }
     }
+  };
+  // The wave empties its OWN queue (no barrier, no other wave involved): one entry per lane, slot in the query's segment
+  // from a returning LDS atomic, all loads / atomics / stores of a pass in flight together.
+  auto wave_flush = [&]() {
+    const unsigned n = wq_cnt < (unsigned)WQE ? wq_cnt : (unsigned)WQE;   // entries beyond WQE went the slow path
+    uint4 en[WQE / 64]; int pos[WQE / 64];
+#pragma unroll
+    for (int j = 0; j < WQE / 64; ++j) en[j] = qent[w][j * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < WQE / 64; ++j) {
+      const bool in = (unsigned)(j * 64 + lane) < n && (int64_t)en[j].y < a.n_virtual;
+      pos[j] = in ? atomicAdd(&qcntS[en[j].z], 1) : a.seg_cap;   // LDS
+    }
+#pragma unroll
+    for (int j = 0; j < WQE / 64; ++j)
+      if (pos[j] < a.seg_cap)
+        a.seg[((size_t)(qb0 + en[j].z) * a.nsplit + by) * a.seg_cap + pos[j]] = make_key(__uint_as_float(en[j].x), en[j].y);
     wq_cnt = 0;
   };
   // after every stage: the barrier hands the LDS tile buffer over.  ALL waves empty their queues at the same stage, as
@@ -460,7 +430,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void scan_bf16_kernel(ScanA
       const unsigned m01 = wcnt[wpar][0] > wcnt[wpar][1] ? wcnt[wpar][0] : wcnt[wpar][1];
       const unsigned m23 = wcnt[wpar][2] > wcnt[wpar][3] ? wcnt[wpar][2] : wcnt[wpar][3];
       wpar ^= 1;
-      if (last || (m01 > m23 ? m01 : m23) >= (unsigned)(WQ - 16)) wave_flush();   // workgroup-uniform decision (a stage adds ~9 columns per wave)
+      if (last || (m01 > m23 ? m01 : m23) >= (unsigned)(WQE - 64)) wave_flush();   // workgroup-uniform decision (a stage adds ~10-20 entries per wave)
     }
   };
   auto compute = [&](int buf, int64_t i) {
@@ -509,6 +479,435 @@ __global__ __launch_bounds__(256, MODE == 0 ? 3 : 2) void scan_bf16_kernel(ScanA
     for (int i = 0; i < SAMPLE_T; ++i) {
       if (ok0) a.cand[(size_t)qr0 * a.cap + slot + i] = make_key(top0[i], 0u);
       if (ok1) a.cand[(size_t)qr1 * a.cap + slot + i] = make_key(top1[i], 0u);
+    }
+  }
+}
+
+// RIHIP_FILTER_WIDE=1 sends batches of more than 512 queries at d = 128 to scan_bf16_wide_kernel (opt-in: see its header)
+static bool filter_wide_enabled() {
+  const char* ev = getenv("RIHIP_FILTER_WIDE");
+  return ev && ev[0] == '1';
+}
+
+// ---- an OPT-IN filter for large batches at d = 128 (round 3 experiment, RIHIP_FILTER_WIDE=1) --------------------------
+// What scan_bf16_kernel leaves on the table at 4 096 queries x 1 M rows, measured by switching parts off
+// (profiles/README.md, "filter ablations"): without any survivor handling it runs 0.78-0.84 ms -- 1.3-1.4 PFLOP/s, at
+// which the chip already holds its clock at ~2.0 GHz (bf16 MFMA on random data is power-limited well below the 2.5 PF
+// of the data sheet) -- and the survivor handling ADDS 0.45-0.55 ms on top.
+// This kernel tries the other end of the design space.  A workgroup is 8 waves = 2 per SIMD with 256 registers each,
+// 128 queries per wave (four 32-query MFMA groups: an LDS fragment feeds four MFMAs; 1 024 queries per workgroup also
+// quarter the L2 -> LDS traffic).  LDS tiles arrive by LDS-DMA (global_load_lds: no staging registers; the 32 registers
+// saved hold k-chunks 0..3 of the NEXT sub-tile, re-read as soon as their MFMAs have issued, and k-chunks 4..7 of the
+// current one), three stage buffers deep, so a DMA has two stages to land.  The LDS image is lane-linear per DMA piece
+// (1 KiB = 4 rows of 256 B) and bank-conflict-free for the fragment reads through an XOR swizzle of the 16-byte chunk
+// index, applied to the DMA's SOURCE address and to the read address alike.  The waves 0-3 and the waves 4-7 run the
+// SAME program -- MFMAs of sub-tile s, barrier, survivors of sub-tile s, barrier -- one phase apart (waves 4-7 take one
+// extra barrier first, waves 0-3 one extra at the end): in every phase each SIMD has one wave on the matrix pipe and
+// one in the survivor code.
+// Measured (tools/filter_ablate.sh, tools/wide_probe.py): MFMA-only 0.76-0.79 ms -- no better than the 3-wave kernel, both
+// sit at the clock the chip holds; complete 1.28-1.33 ms against 1.28-1.33 ms for scan_bf16_kernel.  The survivor phase
+// of one wave costs ~2 100 cycles (264 instructions, a wave alone issues ~1 per 8-10 cycles; the column dump is 20
+// ds_write_b128 at 13 LDS cycles each) against ~1 300 for the partner's 32 MFMAs, so the phases do not balance.  With one
+// barrier per stage instead of four (RIHIP_WIDE_PINGPONG=0) the two drifting waves hide each other's latencies and the
+// kernel runs 1.17-1.23 ms -- but that form loses ~1 survivor in 10 of the queries (tools/filter_check.py; sporadic,
+// any rank, any stage, not cured by full waits or nops: unexplained), so it is NOT offered.  Hence opt-in, not default.
+#ifdef RIHIP_WIDE_PROBE   // diagnostic build: s_memtime stamps of one stage of workgroup 0, waves 0 and 4
+__device__ unsigned long long g_wide_probe[64];
+#define WIDE_STAMP(k) do { if (blockIdx.x == 0 && i == i0 + 20 && (threadIdx.x & 255) == 0) g_wide_probe[(threadIdx.x >> 8) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int rihip_debug_wide_probe(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wide_probe), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : 1;
+}
+#define WIDE_STAMP2(k) do { if (probe_on && blockIdx.x == 0 && (threadIdx.x & 255) == 0) g_wide_probe[32 + (threadIdx.x >> 8) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WIDE_STAMP(k)
+#define WIDE_STAMP2(k)
+#endif
+// 1 (the only form offered): a barrier after EVERY phase holds the two wave halves one phase apart; 0: one barrier per
+// stage, the waves drift -- faster, but it loses survivors (header above): diagnostic builds only.
+#ifndef RIHIP_WIDE_PINGPONG
+#define RIHIP_WIDE_PINGPONG 1
+#endif
+constexpr int QW = 128;          // queries per wave
+constexpr int QB2 = 8 * QW;      // queries per workgroup
+constexpr int ST2 = 64;          // corpus rows per stage (two 32-row MFMA sub-tiles)
+constexpr int NB2 = 3;           // LDS stage buffers
+constexpr int WQC = 64;          // survivor queue: 80-byte columns (16 scores + header) per wave
+constexpr int WIDE_LDS = 8 * WQC * 80 + QB2 * 4;   // 24 576 bytes of dynamic LDS beside the 48 KB of stage buffers
+
+__global__ __launch_bounds__(512, 2) void scan_bf16_wide_kernel(ScanArgs a) {
+  constexpr int D = 128, KB = D / 16;
+  // (the stage buffers are a static array and the queues dynamic LDS ON PURPOSE: hipcc puts `s_waitcnt vmcnt(0)` in front
+  // of every LDS access that may alias a pending LDS-DMA, and it can only tell distinct objects apart)
+  __shared__ __attribute__((aligned(1024))) __bf16 Xs[NB2 * ST2 * D];
+  extern __shared__ __attribute__((aligned(16))) char wide_lds[];
+  char* qcol = wide_lds;                                           // [8][WQC] columns of 80 bytes
+  int* qcntS = reinterpret_cast<int*>(wide_lds + 8 * WQC * 80);    // [QB2] survivors per query in this split
+  const __bf16* Xb = reinterpret_cast<const __bf16*>(a.Xb);
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // (w in a scalar register)
+  const int r31 = lane & 31, hh = lane >> 5;
+  // XCD-aware block map, as in scan_bf16_kernel: the query blocks that stream the same corpus split share an XCD's L2
+  const unsigned lin = blockIdx.x;
+  const unsigned xcd = lin & 7u, kk = lin >> 3;
+  const unsigned bx = kk % (unsigned)a.qgrid, by = (kk / (unsigned)a.qgrid) * 8u + xcd;
+  if ((int)by >= a.nsplit) return;
+  const int64_t qb0 = (int64_t)bx * QB2;
+  float te[4];
+  bf16x8_t qf[4][KB];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int64_t q = qb0 + w * QW + g * 32 + r31;
+    const int64_t qr = q < a.nq ? q : a.nq - 1;
+    te[g] = q < a.nq ? a.thr[qr] : INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const f32x4 u0 = *reinterpret_cast<const f32x4*>(&a.Q[qr * D + kb * 16 + 8 * hh]);
+      const f32x4 u1 = *reinterpret_cast<const f32x4*>(&a.Q[qr * D + kb * 16 + 8 * hh + 4]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { qf[g][kb][j] = (__bf16)u0[j]; qf[g][kb][4 + j] = (__bf16)u1[j]; }
+    }
+  }
+  const unsigned qlb = (unsigned)(w * QW + r31);   // block-local index of the lane's first query (group g: + 32 g)
+  const int64_t n_seq = (a.n_virtual + ST2 - 1) / ST2;
+  const int64_t per = (n_seq + a.nsplit - 1) / a.nsplit;
+  const int64_t i0 = (int64_t)by * per;
+  const int64_t i1 = (i0 + per < n_seq) ? i0 + per : n_seq;
+  if (i0 >= i1) {   // a split without rows: its segments are empty, and SAY so
+    if (hh == 0) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int64_t q = qb0 + w * QW + g * 32 + r31;
+        if (q < a.nq) a.seg_cnt[(size_t)q * a.nsplit + by] = 0;
+      }
+    }
+    return;
+  }
+  if (hh == 0) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) qcntS[qlb + g * 32] = 0;   // own queries only: visible to the wave's own flush in program order
+  }
+
+  // LDS-DMA: wave w issues pieces 2w, 2w+1 of a stage; piece j holds rows 4j .. 4j+3, lane L writes chunk L of the piece
+  // = (row 4j + L/16, stored chunk L%16) and therefore FETCHES chunk (L%16) ^ (row & 15) of that row.  With j = 2w + t
+  // the byte offset of lane L's source in the stage is ((base + 1024 t) ^ (64 t)): one register, re-derived per piece
+  // (the opaque asm keeps hipcc from hoisting 64-bit addresses into registers this kernel does not have).
+  const unsigned dma_base = (unsigned)((w * 8 + (lane >> 4)) * (D * 2)) + (unsigned)((((lane & 15) ^ (lane >> 4) ^ (8 * (w & 1))) & 15) << 4);
+  auto issue_dma = [&](int64_t stage, int buf) {
+    const int64_t v_base = stage * ST2;
+    unsigned ob = dma_base;
+    asm volatile("" : "+v"(ob));
+    // (the bf16 copy is padded with zero rows to a whole stage -- prepare_flat -- and the flush drops rows >= n_virtual)
+    const char* src = reinterpret_cast<const char*>(Xb + (size_t)v_base * D);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ((ob + 1024u * t) ^ (64u * t))),
+                                       (__attribute__((address_space(3))) void*)(&Xs[(size_t)buf * (ST2 * D) + ((w * 2 + t) * 4) * D]), 16, 0, 0);
+  };
+  // fragment (row sub*32 + r31, k chunk 2 kb + hh) sits at chunk (2 kb + hh) ^ (r31 & 15) of its row:
+  // byte offset = row * 256 + 16 * (hh ^ (r31 & 1)) + 32 * (kb ^ ((r31 & 15) >> 1)).
+  // The reads are inline asm ON PURPOSE: hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of every ds_read it can see
+  // while an LDS-DMA that may alias it is pending (it cannot tell the stage buffers apart), which would drain the DMA
+  // issued a few instructions earlier.  The compiler does not track these reads, so their `lgkmcnt` waits are explicit
+  // too (wait_fa / wait_fb: asm that "rewrites" the fragment registers, so no MFMA can be scheduled above it).
+  // The row part, the 16-byte half and the swizzle term leave bits 5..7 of the sum clear for (kb ^ y) << 5, so ONE
+  // register p = base + (y << 5) (+ the stage buffer's offset) gives every fragment address as p ^ (kb << 5): this
+  // kernel has no registers to spare, and a spilled value costs a `vmcnt(0)` -- i.e. a drained DMA -- at its reload.
+  const unsigned xs_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)reinterpret_cast<char*>(&Xs[0]);
+  const unsigned rd_p0 = xs_lds + (unsigned)(r31 * (D * 2)) + (unsigned)((hh ^ (r31 & 1)) << 4) + (unsigned)(((r31 & 15) >> 1) << 5);
+  unsigned rd_p = rd_p0;   // + buffer offset of the stage being read
+  auto read_frag = [&](bf16x8_t& dst, int sub, int kb) {
+    unsigned pk = rd_p;
+    asm volatile("" : "+v"(pk));         // (re-derive the 8 addresses instead of keeping 8 registers)
+    const unsigned addr = pk ^ (unsigned)(kb << 5);
+    if (sub == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
+    else asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(dst) : "v"(addr));
+  };
+  // Survivor handling.  What it costs is INSTRUCTIONS: a wave alone issues one every >= 4 cycles (more beside the partner's
+  // MFMAs) and a taken branch costs ~60, so the per-score branch tree this kernel first had took ~950 cycles per 32x32
+  // tile and a one-tile-at-a-time column dump + a separate flush ~3 000 per phase against ~1 300 for the partner's 32
+  // MFMAs (s_memtime stamps, tools/wide_probe.py).  This form:
+  //  * the four tiles of a sub-tile are handled together (independent maximum chains and slot computations interleave);
+  //  * a lane whose 16-score column holds a survivor dumps the column + a header (query, first row, threshold) into the
+  //    wave's ring of WQC columns -- straight-line code, slot from the ballots; the per-score test happens in the flush,
+  //    64 scores at a time with every lane busy;
+  //  * every phase flushes up to 16 columns queued by EARLIER phases, its LDS reads / atomics / global stores issued
+  //    ahead of, between and behind the steps of the dump so that none of their latencies is waited for idle;
+  //  * all LDS operations of the hot loop are inline asm: hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of every
+  //    LDS access it can see that may alias a pending LDS-DMA, i.e. drains the DMA issued a few hundred cycles earlier.
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  char* qcol_w = qcol + w * (WQC * 80);
+  const unsigned qcol_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)qcol_w;
+  const unsigned qcnt_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)reinterpret_cast<char*>(qcntS);
+  const int seg_sh = 31 - __builtin_clz((unsigned)a.seg_cap);   // (a power of two: see the host side)
+  unsigned q_head = 0, q_tail = 0;   // wave-uniform ring indices (columns q_head .. q_tail-1 are queued, slot = index % WQC)
+  bool q_over = false;               // the ring overflowed: all of the wave's queries take the exact re-do
+  // (within every step the four tiles / four batch passes are computed side by side and only then come the predicated
+  // LDS / global operations: a wave alone pays ~10 cycles per DEPENDENT instruction and ~4 per independent one)
+  const unsigned nv32 = (unsigned)(a.n_virtual < 0xFFFFFFFFll ? a.n_virtual : 0xFFFFFFFFll);
+  bool probe_on = false;
+  auto survivor_phase = [&](const f32x16& a0, const f32x16& a1, const f32x16& a2, const f32x16& a3, unsigned vl, bool dump, bool flush) {
+    WIDE_STAMP2(0);
+    // ---- A: reads of the flush batch
+    unsigned ln = (unsigned)lane;
+    asm volatile("" : "+v"(ln));   // (keeps hipcc from holding lane-derived constants in registers across the MFMA phases)
+    const unsigned e = ln & 15u, cj = ln >> 4;
+    const unsigned ve = (e & 3u) + 8u * (e >> 2);
+    const unsigned nb = q_tail - q_head < 16u ? q_tail - q_head : 16u;
+    u32x4_t hd[4]; float sc[4]; int pos[4];
+    if (flush) {
+      unsigned cadr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cadr[j] = qcol_lds + ((q_head + 4u * j + cj) & (unsigned)(WQC - 1)) * 80u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        asm volatile("ds_read_b128 %0, %2 offset:64\n\tds_read_b32 %1, %3" : "=v"(hd[j]), "=v"(sc[j]) : "v"(cadr[j]), "v"(cadr[j] + 4u * e));
+    }
+    WIDE_STAMP2(1);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- B: column maxima of the four new tiles (inline-asm v_max3 must not be the first reader of an MFMA result --
+    // the hazard recognizer does not see it: each chain is seeded through a compiler-visible move)
+    unsigned long long b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+    bool h0 = false, h1 = false, h2 = false, h3 = false;
+    if (dump) {
+      float m0 = a0[15], m1 = a1[15], m2 = a2[15], m3 = a3[15];
+      asm volatile("" : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3));
+#pragma unroll
+      for (int r = 0; r < 14; r += 2) {
+        m0 = max3_raw(m0, a0[r], a0[r + 1]);
+        m1 = max3_raw(m1, a1[r], a1[r + 1]);
+        m2 = max3_raw(m2, a2[r], a2[r + 1]);
+        m3 = max3_raw(m3, a3[r], a3[r + 1]);
+      }
+      m0 = max3_raw(m0, a0[14], a0[14]); m1 = max3_raw(m1, a1[14], a1[14]);
+      m2 = max3_raw(m2, a2[14], a2[14]); m3 = max3_raw(m3, a3[14], a3[14]);
+#if RIHIP_SCAN_ABLATE != 1   // (1: experiments without survivor handling)
+      h0 = m0 >= te[0]; h1 = m1 >= te[1]; h2 = m2 >= te[2]; h3 = m3 >= te[3];
+#else
+      asm volatile("" :: "v"(m0), "v"(m1), "v"(m2), "v"(m3));
+#endif
+      b0 = __ballot(h0); b1 = __ballot(h1); b2 = __ballot(h2); b3 = __ballot(h3);
+    }
+    WIDE_STAMP2(2);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- C: per-score test of the flush batch, slots in the queries' segments (returning LDS atomics)
+    if (flush) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hd[0]), "+v"(hd[1]), "+v"(hd[2]), "+v"(hd[3]), "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3]));
+      bool hit[4]; unsigned cadr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        hit[j] = 4u * j + cj < nb && sc[j] >= __uint_as_float(hd[j].z) && hd[j].y + ve < nv32;
+        cadr[j] = qcnt_lds + 4u * hd[j].w;
+        pos[j] = a.seg_cap;
+      }
+      const unsigned one = 1u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (hit[j]) asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(pos[j]) : "v"(cadr[j]), "v"(one) : "memory");
+      q_head += nb;
+    }
+    WIDE_STAMP2(3);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- D: column dump of the new tiles
+    if (dump) {
+      const unsigned n0 = (unsigned)__popcll(b0), n1 = (unsigned)__popcll(b1), n2 = (unsigned)__popcll(b2), n3 = (unsigned)__popcll(b3);
+      const unsigned base1 = q_tail + n0, base2 = base1 + n1, base3 = base2 + n2, tail2 = base3 + n3;
+      q_over = q_over || tail2 - q_head > (unsigned)WQC;   // (q_head already advanced: the batch's reads are older LDS operations)
+      unsigned qx = qlb;
+      asm volatile("" : "+v"(qx));   // (derived here: hipcc would otherwise hold four query indices in registers)
+      auto slot = [&](unsigned long long bal, unsigned base) -> unsigned {
+        const unsigned p2 = base + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+        return qcol_lds + (p2 & (unsigned)(WQC - 1)) * 80u;
+      };
+      const unsigned d0 = slot(b0, q_tail), d1 = slot(b1, base1), d2 = slot(b2, base2), d3 = slot(b3, base3);
+      auto put = [&](const f32x16& acc, bool h, unsigned dst, int g) {
+        if (h) {
+          const f32x4 s0 = {acc[0], acc[1], acc[2], acc[3]}, s1 = {acc[4], acc[5], acc[6], acc[7]};
+          const f32x4 s2 = {acc[8], acc[9], acc[10], acc[11]}, s3 = {acc[12], acc[13], acc[14], acc[15]};
+          const u32x4_t hdr = {vl, vl, __float_as_uint(te[g]), qx + (unsigned)(g * 32)};
+          asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:16\n\tds_write_b128 %0, %3 offset:32\n\t"
+                       "ds_write_b128 %0, %4 offset:48\n\tds_write_b128 %0, %5 offset:64"
+                       :: "v"(dst), "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(hdr) : "memory");
+        }
+      };
+      put(a0, h0, d0, 0);
+      put(a1, h1, d1, 1);
+      put(a2, h2, d2, 2);
+      put(a3, h3, d3, 3);
+      q_tail = tail2;
+    }
+    WIDE_STAMP2(4);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- E: the flush batch's survivors to their segments
+    if (flush) {
+      uint64_t* dstp[4]; uint64_t key[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned seg_i = __umul24((unsigned)qb0 + hd[j].w, (unsigned)a.nsplit) + by;
+        dstp[j] = a.seg + ((size_t)seg_i << seg_sh);
+        key[j] = make_key(sc[j], hd[j].y + ve);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pos[0]), "+v"(pos[1]), "+v"(pos[2]), "+v"(pos[3]));
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (pos[j] < a.seg_cap) dstp[j][(unsigned)pos[j]] = key[j];
+    }
+    WIDE_STAMP2(5);
+  };
+  auto phase_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+
+  // prologue: stages i0 and i0+1 in flight, k-chunks 0..3 of (i0, sub-tile 0) read
+  issue_dma(i0, 0);
+  if (i0 + 1 < i1) {
+    issue_dma(i0 + 1, 1);
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  phase_barrier();
+  // Fragment registers: fa = k chunks 0..3 of the NEXT sub-tile (read while the current one's MFMAs issue, in flight
+  // during its survivor handling), fb = k chunks 4..7 of the CURRENT one (read at the start of its MFMA phase, 512 MFMA
+  // cycles before their use; dead during the survivor handling, which is where the register pressure peaks).
+  bf16x8_t fa[4], fb[4];
+  auto wait_fa = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3])); };
+  auto wait_fb4 = [&]() { asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3])); };
+  auto wait_fb0 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3])); };
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) read_frag(fa[kb], 0, kb);
+#if RIHIP_WIDE_PINGPONG
+  if (w >= 4) phase_barrier();   // waves 4-7 run one phase behind waves 0-3
+#endif
+  int buf = 0;
+#pragma unroll 1
+  for (int64_t i = i0; i < i1; ++i) {
+    // (the survivor phases' global stores count in vmcnt like the DMA pieces; wherever they fall in the issue order, the
+    // counted wait below still covers everything older than the two youngest operations, i.e. this wave's pieces of
+    // stage i+1)
+    // buffer (i+2) % 3 was last read in the phase that ended with the barrier this wave has just passed
+    const int buf2 = buf >= 1 ? buf - 1 : 2;
+    if (i + 2 < i1) issue_dma(i + 2, buf2);
+    const unsigned vb = (unsigned)(i * ST2) + 4u * (unsigned)hh;
+    f32x16 c0, c1, c2, c3;
+    WIDE_STAMP(0);
+    wait_fa();
+    {   // MFMAs of sub-tile 0
+      c0 = zero16(); c1 = zero16(); c2 = zero16(); c3 = zero16();
+#if RIHIP_SCAN_ABLATE == 11   // experiments: waves 4-7 issue no MFMAs (the survivor phases of waves 0-3 run uncontended)
+      if (w < 4)
+#endif
+      {
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) read_frag(fb[kb], 0, 4 + kb);
+      __builtin_amdgcn_sched_barrier(0);   // (hipcc's scheduler otherwise sinks these reads to just before their wait)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kb], qf[0][kb], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kb], qf[1][kb], c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kb], qf[2][kb], c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kb], qf[3][kb], c3, 0, 0, 0);
+        read_frag(fa[kb], 1, kb);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      wait_fb4();
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kb], qf[0][4 + kb], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kb], qf[1][4 + kb], c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kb], qf[2][4 + kb], c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kb], qf[3][4 + kb], c3, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      }
+    }
+    WIDE_STAMP(1);
+#if RIHIP_WIDE_PINGPONG
+    phase_barrier();
+#endif
+    WIDE_STAMP(2);
+    probe_on = (i == i0 + 20);
+    survivor_phase(c0, c1, c2, c3, vb, true, q_tail - q_head >= 12u);   // (a sub-tile brings ~7 columns at k = 500: a batch of <= 16 every other phase)
+    probe_on = false;
+    WIDE_STAMP(3);
+    while (__builtin_expect(q_tail - q_head > 32u, 0)) survivor_phase(c0, c1, c2, c3, vb, false, true);   // (dense survivors)
+    WIDE_STAMP(4);
+#if RIHIP_WIDE_PINGPONG
+    phase_barrier();
+#endif
+    WIDE_STAMP(5);
+    wait_fa();
+    {   // MFMAs of sub-tile 1
+      c0 = zero16(); c1 = zero16(); c2 = zero16(); c3 = zero16();
+#if RIHIP_SCAN_ABLATE == 11
+      if (w < 4)
+#endif
+      {
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) read_frag(fb[kb], 1, 4 + kb);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kb], qf[0][kb], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kb], qf[1][kb], c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kb], qf[2][kb], c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kb], qf[3][kb], c3, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      wait_fb0();
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kb], qf[0][4 + kb], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kb], qf[1][4 + kb], c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kb], qf[2][4 + kb], c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kb], qf[3][4 + kb], c3, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      }
+    }
+    // this wave's pieces of stage i+1 have landed (the barriers add the other waves': the first reader of stage i+1 is
+    // two barriers away for waves 0-3's pieces and one for waves 4-7's); the DMA of stage i+2 stays in flight
+    if (i + 2 < i1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WIDE_STAMP(6);
+    phase_barrier();
+    WIDE_STAMP(7);
+    survivor_phase(c0, c1, c2, c3, vb + 32u, true, q_tail - q_head >= 12u);
+    WIDE_STAMP(8);
+    while (__builtin_expect(q_tail - q_head > 32u, 0)) survivor_phase(c0, c1, c2, c3, vb + 32u, false, true);
+    WIDE_STAMP(9);
+#if RIHIP_WIDE_PINGPONG
+    phase_barrier();
+#endif
+    WIDE_STAMP(10);
+    buf = buf == 2 ? 0 : buf + 1;
+    rd_p = rd_p0 + (unsigned)buf * (unsigned)(ST2 * D * 2);
+    if (i + 1 < i1) {
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) read_frag(fa[kb], 0, kb);
+    }
+  }
+#if RIHIP_WIDE_PINGPONG
+  if (w < 4) phase_barrier();    // (every wave passes the same number of barriers)
+#endif
+  {
+    f32x16 z = zero16();
+    while (q_tail != q_head) survivor_phase(z, z, z, z, 0u, false, true);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (q_over && hh == 0) {   // ring overflow (a sub-tile brought more columns than the ring had free: dense survivors)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) atomicOr(&qcntS[qlb + g * 32], 1 << 30);
+  }
+  {   // the wave's own LDS atomics are complete (in order): publish the segment fills.  (Lane -> query mapping derived
+      // again from the thread index: keeping the prologue's values alive through the loop costs registers.)
+    unsigned t2 = threadIdx.x;
+    asm volatile("" : "+v"(t2));
+    if (((t2 >> 5) & 1u) == 0u) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int qlg = (int)(t2 >> 6) * QW + g * 32 + (int)(t2 & 31u);
+        if (qb0 + qlg < a.nq) a.seg_cnt[(size_t)(qb0 + qlg) * a.nsplit + by] = qcntS[qlg];
+      }
     }
   }
 }
@@ -1680,10 +2079,21 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
     if (ns > 65535) ns = 65535;
     return (int)ns;
   };
+  // the filter of a large batch at d = 128 takes the 1 024-query workgroups of scan_bf16_wide_kernel (1 resident per CU)
+  const bool wide = two_prec && d == 128 && nq > 2 * QBB && filter_wide_enabled();
+  const unsigned qgrid_w = (unsigned)((nq + QB2 - 1) / QB2);
+  auto wide_nsplit = [&](int64_t tiles) -> int {
+    int64_t ns = (RIHIP_NCU + qgrid_w - 1) / qgrid_w;
+    if (ns > tiles) ns = tiles;
+    if (ns < 1) ns = 1;
+    if (ns > 1024) ns = 1024;
+    return (int)ns;
+  };
   if (two_prec) {
-    const int ns_main = bf16_nsplit((h->N + TRB - 1) / TRB);
+    const int ns_main = wide ? wide_nsplit((h->N + ST2 - 1) / ST2) : bf16_nsplit((h->N + TRB - 1) / TRB);
     while ((double)seg_cap < 4.0 * expect / ns_main) seg_cap <<= 1;
     if ((int64_t)seg_cap > cap) seg_cap = (int)cap;
+    if (wide) while (seg_cap & (seg_cap - 1)) seg_cap &= seg_cap - 1;   // (the wide filter addresses segments by a shift)
   }
   const int64_t sample_tiles = (S + (two_prec ? TRB : TRS) - 1) / (two_prec ? TRB : TRS);
   // The sample pass keeps the SAMPLE_T best scores of every stream (query x corpus split x row half) in registers
@@ -1697,13 +2107,24 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
     ScanArgs x = args;
     if (two_prec) {
       x.Xb = h->Xb;
-      x.nsplit = bf16_nsplit(tiles, x.dense ? 2 : 3);
-      x.qgrid = (int)qgrid_b;
+      const bool use_wide = wide && !x.dense;
+      x.nsplit = use_wide ? wide_nsplit(tiles) : bf16_nsplit(tiles, x.dense ? 2 : 3);
+      x.qgrid = use_wide ? (int)qgrid_w : (int)qgrid_b;
       if (!x.dense) {
         RIHIP_REQUIRE(x.nsplit <= 1024, RIHIP_ERR_SHAPE, "ip_index: %d corpus splits", x.nsplit);
         RCCHK(h->seg.reserve(nq * x.nsplit * seg_cap));
         RCCHK(h->seg_cnt.reserve(nq * x.nsplit));
         x.seg = h->seg.p; x.seg_cnt = h->seg_cnt.p; x.seg_cap = seg_cap; main_nsplit = x.nsplit;
+      }
+      if (use_wide) {
+        const dim3 gridw(qgrid_w * 8u * (unsigned)((x.nsplit + 7) / 8));
+        static bool wide_granted = false;
+        if (!wide_granted) {
+          HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(scan_bf16_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS));
+          wide_granted = true;
+        }
+        hipLaunchKernelGGL(scan_bf16_wide_kernel, gridw, dim3(512), WIDE_LDS, st, x);
+        return check_launch("scan_bf16_wide");
       }
       const dim3 grid(qgrid_b * 8u * (unsigned)((x.nsplit + 7) / 8));
       const int mode = x.dense ? (sample_top ? 2 : 1) : 0;
@@ -1833,7 +2254,10 @@ int prepare_flat(IpIndex* h, hipStream_t st) {
   const int64_t n = h->N * h->d;
   hipFree(h->Xb);
   h->Xb = nullptr;
-  HIPCHK(hipMalloc((void**)&h->Xb, sizeof(__bf16) * (size_t)n));
+  // (rows padded with zeros to a whole 64-row stage: the LDS-DMA filter has no partial-stage path)
+  const int64_t n_pad = ((h->N + ST2 - 1) / ST2) * ST2 * h->d;
+  HIPCHK(hipMalloc((void**)&h->Xb, sizeof(__bf16) * (size_t)n_pad));
+  if (n_pad > n) HIPCHK(hipMemsetAsync(h->Xb + n, 0, sizeof(__bf16) * (size_t)(n_pad - n), st));
   hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, st, h->X, n, h->Xb);
   int* bits = nullptr;
   HIPCHK(hipMalloc((void**)&bits, sizeof(int)));

@@ -225,6 +225,40 @@ def test_two_precision_search_equals_all_f32():
         assert set(r1[q]) == set(r2[q]) or np.abs(s1[q, -1] - s1[q, -2]) < 1e-6
 
 
+def test_wide_filter_equals_the_narrow_filter_and_all_f32(monkeypatch):
+    """`RIHIP_FILTER_WIDE=1` sends batches of more than 512 queries at d = 128 to the 1 024-query LDS-DMA filter
+    (`scan_bf16_wide_kernel`, an opt-in experiment: DESIGN.md section 9); it must hand the re-score the same survivors as
+    the 256-query filter: identical results, also on a corpus that is not a whole number of 64-row stages, with a partly
+    filled last query block and with self-matches."""
+    from recommendit_amd import FAISSIndex, _lib
+    rng = np.random.RandomState(21)
+    N, d, nq, k = 150_003, 128, 700, 500
+    X, Q = fx.unit_rows(rng, N, d), fx.unit_rows(rng, nq, d)
+    Q[:5] = X[-5:]                                 # self-matches in the last (partial) stage
+    idx = FAISSIndex(embed_dim=d, exact=True)
+    idx.build_ivf_index(X, list(range(N)))
+    sn, rn = idx.batch_search(Q, k=k)              # 256-query filter (the default)
+    monkeypatch.setenv("RIHIP_FILTER_WIDE", "1")
+    sw, rw = idx.batch_search(Q, k=k)              # wide filter
+    # the same survivors reach the exact re-score; its f32 summation order depends on where a candidate sits in its
+    # segment, so scores may differ in the last bit and near-ties may swap places: same SETS, scores to 1e-6
+    np.testing.assert_allclose(sw, sn, atol=1e-6, rtol=0)
+    for q in range(nq):
+        assert set(rw[q]) == set(rn[q]) or np.abs(sn[q, -1] - sn[q, -2]) < 1e-6, q
+    assert (rw == rn).mean() > 0.999
+    assert (rw[:5, 0] == np.arange(N - 5, N)).all()
+    sel = rng.choice(nq, 32, replace=False)
+    _check_topk(sw[sel], rw[sel], Q[sel], X, k)
+    _lib.check(_lib.lib().rihip_ip_index_set_two_precision(idx.index._h, 0))
+    s1, r1 = idx.batch_search(Q, k=k)              # all-f32
+    np.testing.assert_allclose(sw, s1, atol=1e-6, rtol=0)
+    assert (r1 == rw).mean() > 0.999
+    for k2 in (10, 100):                           # other k (other thresholds / segment capacities) on the same index
+        _lib.check(_lib.lib().rihip_ip_index_set_two_precision(idx.index._h, 1))
+        s2, r2 = idx.batch_search(Q, k=k2)
+        _check_topk(s2[sel], r2[sel], Q[sel], X, k2)
+
+
 def test_two_precision_scratch_reuse_across_batch_sizes():
     """The filter's per-(query, corpus split) segments live in scratch that is reused by later calls with another
     number of splits; splits that get no rows (the split count does not divide the stages) must still publish an empty

@@ -8,6 +8,11 @@ import numpy as np
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import os  # noqa: E402
+
+if os.environ.get("RIHIP_LIB"):   # experiments: another build of the library (ablation variants of one kernel)
+    from recommendit_amd import _lib as _L  # noqa: E402
+    _L.LIB_PATH = Path(os.environ["RIHIP_LIB"]).resolve()
 from recommendit_amd import FAISSIndex  # noqa: E402
 
 nq = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
