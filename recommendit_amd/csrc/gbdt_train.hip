@@ -53,8 +53,10 @@ namespace {
 
 constexpr int NBIN = 256;
 constexpr int HCH = 1024;        // rows per histogram workgroup: 1024 x 2^20 < 2^31 keeps int32 sums exact
-constexpr int FCH = 50;          // features per histogram pass (50 x 256 x 3 x 4 B = 150 KB of LDS; 25 with 8-byte cells):
-                                 // the reference's 50 ranking features in ONE pass over the rows
+constexpr int FCH = 10;          // features per histogram WORKGROUP (10 x 256 x 3 x 4 B = 30 KB of LDS; 5 with 8-byte cells):
+                                 // grid = (row chunks, feature chunks), one launch per histogram.  (All 50 features in one
+                                 // 150 KB workgroup -- 1 per CU -- took 55 us per call: zeroing and flushing 38 400 cells
+                                 // cost as much as the 1 024 rows, with nothing else resident to overlap them.)
 constexpr int MAX_GROUP = 16384; // documents per query (sorted scores + labels of a query live in LDS)
 constexpr int MAX_T = 32;        // truncation level supported by the per-thread pair accumulators
 constexpr double QLEVELS = 1048576.0;
@@ -192,16 +194,25 @@ __global__ __launch_bounds__(256) void lambdarank_kernel(GradArgs a) {
 }
 
 // rank-order lambdas -> document order, and the largest magnitudes (for the quantisation scale)
-__global__ void unsort_absmax_kernel(const double* __restrict__ ls, const double* __restrict__ hs, const int* __restrict__ sorted,
+__global__ __launch_bounds__(256) void unsort_absmax_kernel(const double* __restrict__ ls, const double* __restrict__ hs, const int* __restrict__ sorted,
                                      int64_t n, double* lam, double* hes, unsigned long long* mx) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  double g = 0.0, h = 0.0;
-  if (i < n) { g = ls[i]; h = hs[i]; lam[sorted[i]] = g; hes[sorted[i]] = h; }
-  g = fabs(g);
-  for (int o = 32; o > 0; o >>= 1) { g = fmax(g, __shfl_xor(g, o, 64)); h = fmax(h, __shfl_xor(h, o, 64)); }
-  if ((threadIdx.x & 63) == 0) {   // non-negative doubles order like their bit patterns
-    atomicMax(&mx[0], (unsigned long long)__double_as_longlong(g));
-    atomicMax(&mx[1], (unsigned long long)__double_as_longlong(h));
+  // (one atomic pair per workgroup of a grid-stride loop: one per WAVE of a 9 000-workgroup grid serialised 75 000
+  // same-address atomics in L2 -- 0.85 ms per tree for 38 MB of traffic)
+  __shared__ double wg[4], wh[4];
+  double gm = 0.0, hm = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double g = ls[i], h = hs[i];
+    const int d = sorted[i];
+    lam[d] = g; hes[d] = h;
+    gm = fmax(gm, fabs(g)); hm = fmax(hm, h);
+  }
+  for (int o = 32; o > 0; o >>= 1) { gm = fmax(gm, __shfl_xor(gm, o, 64)); hm = fmax(hm, __shfl_xor(hm, o, 64)); }
+  if ((threadIdx.x & 63) == 0) { wg[threadIdx.x >> 6] = gm; wh[threadIdx.x >> 6] = hm; }
+  __syncthreads();
+  if (threadIdx.x == 0) {   // non-negative doubles order like their bit patterns
+    gm = fmax(fmax(wg[0], wg[1]), fmax(wg[2], wg[3])); hm = fmax(fmax(wh[0], wh[1]), fmax(wh[2], wh[3]));
+    atomicMax(&mx[0], (unsigned long long)__double_as_longlong(gm));
+    atomicMax(&mx[1], (unsigned long long)__double_as_longlong(hm));
   }
 }
 template <typename T>
@@ -216,8 +227,10 @@ __global__ void quantize_kernel(const double* __restrict__ lam, const double* __
 template <typename T>
 __global__ __launch_bounds__(256) void hist_kernel(const uint8_t* __restrict__ Xb, int F, const int* __restrict__ rows,
                                                    int64_t b0, int64_t len, const T* __restrict__ gq,
-                                                   const T* __restrict__ hq, int f0, int nf, long long* hist) {
+                                                   const T* __restrict__ hq, int fch, long long* hist) {
   extern __shared__ __attribute__((aligned(16))) unsigned char hs_raw[];   // [nf][NBIN][3] of T
+  const int f0 = blockIdx.y * fch;
+  const int nf = F - f0 < fch ? F - f0 : fch;
   T* hs = reinterpret_cast<T*>(hs_raw);
   using U = typename std::conditional<sizeof(T) == 8, unsigned long long, int>::type;
   const int tid = threadIdx.x;
@@ -225,6 +238,8 @@ __global__ __launch_bounds__(256) void hist_kernel(const uint8_t* __restrict__ X
   __syncthreads();
   const int64_t c0 = (int64_t)blockIdx.x * HCH;
   const int64_t c1 = (c0 + HCH < len) ? c0 + HCH : len;
+  // (one row at a time per thread.  Handling a thread's four rows side by side -- ids, then gradients and bin bytes, then
+  // the atomics -- was measured slower in both orders: 58 and 70 us per call against 43)
   for (int64_t i = c0 + tid; i < c1; i += 256) {
     const int r = rows[b0 + i];
     const T g = gq[r], h = hq[r];
@@ -258,32 +273,32 @@ __device__ __forceinline__ double leaf_gain(double G, double H, double l1, doubl
 // identical partitions): order 0 = lowest threshold first; order 1 = FeatureHistogram::FindBestThreshold: the
 // right-to-left scan first (highest threshold first, missing rows left), then the left-to-right scan (missing right),
 // a later candidate replaces an earlier one only if its gain is strictly larger.
-__global__ __launch_bounds__(1024) void split_kernel(const long long* __restrict__ hist0, const long long* __restrict__ hist1,
-                                                     int F, const int* __restrict__ nb, const int* __restrict__ nanbin,
-                                                     const unsigned char* __restrict__ used, double sg, double sh, double l1,
-                                                     double l2, int min_child, double min_hess, int order, SplitInfo* out0,
-                                                     const long long* __restrict__ sub_small, int sub_child) {
-  constexpr int NWV = 16;
-  __shared__ SplitInfo best_w[NWV];
-  const long long* hist = blockIdx.x == 0 ? hist0 : hist1;
-  SplitInfo* out = out0 + blockIdx.x;
-  if (!hist) return;   // this child is not split further
+// One wave per (child, feature): grid = (ceil(F / 4), children), 4 waves per workgroup (the first form ran ONE workgroup
+// per child over all features: 24-38 us on 2 of 256 CUs, a quarter of a tree's time).  Every wave writes its feature's
+// best candidate; the last workgroup to finish (device counter, reset by it) picks each child's best feature -- lower
+// feature index among equal gains, whatever the order the workgroups ran in.
+// `sub_small` (the larger child of a split): its histogram is parent - smaller child, formed here bin by bin in the
+// registers of the lane that owns the bin and written back in place, in the parent's slot.
+__global__ __launch_bounds__(256) void split_kernel(const long long* __restrict__ hist0, const long long* __restrict__ hist1,
+                                                    int F, const int* __restrict__ nb, const int* __restrict__ nanbin,
+                                                    const unsigned char* __restrict__ used, double sg, double sh, double l1,
+                                                    double l2, int min_child, double min_hess, int order, SplitInfo* out0,
+                                                    const long long* __restrict__ sub_small, int sub_child,
+                                                    SplitInfo* feat_best, unsigned* done_counter) {
+  __shared__ int is_last;
+  const int child = blockIdx.y;
+  const long long* hist = child == 0 ? hist0 : hist1;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  if (sub_small && (int)blockIdx.x == sub_child) {
-    // the larger child of a split: its histogram is parent - smaller child, formed here, in place in the parent's slot
-    // (what was a launch of its own); the workgroup then reads what it wrote
-    long long* hw = const_cast<long long*>(hist);
-    for (int i = tid; i < F * NBIN * 3; i += 1024) hw[i] -= sub_small[i];
-    __syncthreads();
-  }
+  const int f = blockIdx.x * 4 + w;
   SplitInfo best; best.gain = 0.0; best.feature = -1; best.bin = 0; best.glq = best.hlq = best.cl = 0; best.gq = best.hq = best.c = 0;
   best.default_left = 1; best.pad = 0;
-  for (int f = w; f < F; f += NWV) {
+  if (hist && f < F && used[f] && nb[f] >= 2) {   // (a null histogram: this child is not split further)
     const int nbf = nb[f];
     const int nbn = nanbin[f];
     const int nr = nbn >= 0 ? nbf - 1 : nbf;      // real bins
-    if (!used[f] || nbf < 2) continue;
-    const long long* h = hist + (size_t)f * NBIN * 3;
+    long long* h = const_cast<long long*>(hist) + (size_t)f * NBIN * 3;
+    const bool sub = sub_small && child == sub_child;
+    const long long* hsm = sub ? sub_small + (size_t)f * NBIN * 3 : nullptr;
     // lane l owns bins 4l..4l+3: local sums, then an exclusive prefix over the lanes
     long long g4[4], h4[4], c4[4];
     long long gs = 0, hsum = 0, cs = 0;
@@ -291,8 +306,22 @@ __global__ __launch_bounds__(1024) void split_kernel(const long long* __restrict
     for (int k = 0; k < 4; ++k) {
       const int bb = 4 * lane + k;
       g4[k] = bb < nbf ? h[bb * 3] : 0; h4[k] = bb < nbf ? h[bb * 3 + 1] : 0; c4[k] = bb < nbf ? h[bb * 3 + 2] : 0;
-      gs += g4[k]; hsum += h4[k]; cs += c4[k];
+      if (sub && bb < nbf) {
+        g4[k] -= hsm[bb * 3]; h4[k] -= hsm[bb * 3 + 1]; c4[k] -= hsm[bb * 3 + 2];
+        h[bb * 3] = g4[k]; h[bb * 3 + 1] = h4[k]; h[bb * 3 + 2] = c4[k];
+      }
     }
+    // the missing bin (the last one) from its owner's registers: the value in memory may not be the subtracted one yet
+    long long NG = 0, NH = 0, NC = 0;
+    if (nbn >= 0) {
+      const int k0 = nbn & 3, l0 = nbn >> 2;
+      const long long sg4 = k0 == 0 ? g4[0] : k0 == 1 ? g4[1] : k0 == 2 ? g4[2] : g4[3];
+      const long long sh4 = k0 == 0 ? h4[0] : k0 == 1 ? h4[1] : k0 == 2 ? h4[2] : h4[3];
+      const long long sc4 = k0 == 0 ? c4[0] : k0 == 1 ? c4[1] : k0 == 2 ? c4[2] : c4[3];
+      NG = __shfl(sg4, l0, 64); NH = __shfl(sh4, l0, 64); NC = __shfl(sc4, l0, 64);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { gs += g4[k]; hsum += h4[k]; cs += c4[k]; }
     long long pg = gs, phh = hsum, pc = cs;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -300,8 +329,6 @@ __global__ __launch_bounds__(1024) void split_kernel(const long long* __restrict
       if (lane >= o) { pg += tg; phh += th; pc += tc; }
     }
     const long long TG = __shfl(pg, 63, 64), TH = __shfl(phh, 63, 64), TC = __shfl(pc, 63, 64);
-    long long NG = 0, NH = 0, NC = 0;             // the missing bin
-    if (nbn >= 0) { NG = h[nbn * 3]; NH = h[nbn * 3 + 1]; NC = h[nbn * 3 + 2]; }
     long long cg = pg - gs, ch = phh - hsum, cc = pc - cs;   // exclusive
     const double G = sg > 0.0 ? (double)TG / sg : 0.0, H = sh > 0.0 ? (double)TH / sh : 0.0;
     const double parent = leaf_gain(G, H, l1, l2);
@@ -339,21 +366,57 @@ __global__ __launch_bounds__(1024) void split_kernel(const long long* __restrict
       const bool take = ob >= 0 && (bb_best < 0 || og > bg || (og == bg && oo < bord));
       if (take) { bg = og; bb_best = ob; bord = oo; bdl = od; bgl = ogl; bhl = ohl; bcl = ocl; }
     }
-    if (bb_best >= 0 && (best.feature < 0 || bg > best.gain)) {   // features ascending within the wave: ties keep the lower one
+    if (bb_best >= 0) {
       best.gain = bg; best.feature = f; best.bin = bb_best; best.glq = bgl; best.hlq = bhl; best.cl = bcl;
       best.gq = TG; best.hq = TH; best.c = TC; best.default_left = bdl;
     }
   }
-  if (lane == 0) best_w[w] = best;
+  if (f < F && lane == 0) feat_best[(size_t)child * F + f] = best;
+  // ---- the last workgroup to arrive reduces over the features
+  __threadfence();
   __syncthreads();
   if (tid == 0) {
-    SplitInfo b = best_w[0];
-    for (int k = 1; k < NWV; ++k) {
-      const SplitInfo& o = best_w[k];
-      if (o.feature >= 0 && (b.feature < 0 || o.gain > b.gain || (o.gain == b.gain && o.feature < b.feature))) b = o;
-    }
-    *out = b;
+    const unsigned total = gridDim.x * gridDim.y;
+    is_last = atomicAdd(done_counter, 1u) == total - 1u;
   }
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  if (w < (int)gridDim.y) {   // wave c: child c
+    SplitInfo b = best;        // (any value: replaced below)
+    b.feature = -1; b.gain = 0.0;
+    double bgain = 0.0; int bfeat = -1;
+    for (int f0 = 0; f0 < F; f0 += 64) {
+      const int ff = f0 + lane;
+      double gsel = 0.0; int fsel = -1;
+      if (ff < F) {
+        const SplitInfo* q = &feat_best[(size_t)w * F + ff];
+        const int qf = __builtin_nontemporal_load(&q->feature);
+        if (qf >= 0) { fsel = qf; gsel = __builtin_nontemporal_load(&q->gain); }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double og = __shfl_xor(gsel, o, 64);
+        const int of = __shfl_xor(fsel, o, 64);
+        if (of >= 0 && (fsel < 0 || og > gsel || (og == gsel && of < fsel))) { gsel = og; fsel = of; }
+      }
+      if (fsel >= 0 && (bfeat < 0 || gsel > bgain)) { bgain = gsel; bfeat = fsel; }   // chunks ascend: ties keep the lower feature
+    }
+    if (lane == 0) {
+      if (bfeat >= 0) {
+        const SplitInfo* q = &feat_best[(size_t)w * F + bfeat];
+        SplitInfo r;
+        r.gain = __builtin_nontemporal_load(&q->gain); r.feature = bfeat; r.bin = __builtin_nontemporal_load(&q->bin);
+        r.glq = __builtin_nontemporal_load(&q->glq); r.hlq = __builtin_nontemporal_load(&q->hlq); r.cl = __builtin_nontemporal_load(&q->cl);
+        r.gq = __builtin_nontemporal_load(&q->gq); r.hq = __builtin_nontemporal_load(&q->hq); r.c = __builtin_nontemporal_load(&q->c);
+        r.default_left = __builtin_nontemporal_load(&q->default_left); r.pad = 0;
+        out0[w] = r;
+      } else {
+        out0[w] = b;
+      }
+    }
+  }
+  if (tid == 0) *done_counter = 0u;   // ready for the next launch (launches on one stream do not overlap)
 }
 
 // Partition of a leaf's rows in ONE launch: left = bin <= threshold bin, the rows of the feature's missing bin follow the
@@ -682,7 +745,7 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
   int *rowsA = nullptr, *rowsB = nullptr, *d_cur = nullptr;
   int *d_feat = nullptr, *d_bin = nullptr, *d_lc = nullptr, *d_rc = nullptr;
   long long* hist = nullptr; long long* d_sum = nullptr; unsigned long long* d_mx = nullptr; unsigned char* d_used = nullptr;
-  SplitInfo* d_split = nullptr;
+  SplitInfo* d_split = nullptr; SplitInfo* d_featbest = nullptr; unsigned* d_done = nullptr;
   hipMalloc((void**)&ls, sizeof(double) * n); hipMalloc((void**)&hs, sizeof(double) * n);
   hipMalloc((void**)&lam, sizeof(double) * n); hipMalloc((void**)&hes, sizeof(double) * n);
   hipMalloc(&gq, (wide ? 8 : 4) * (size_t)n); hipMalloc(&hq, (wide ? 8 : 4) * (size_t)n);
@@ -691,6 +754,8 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
   hipMalloc((void**)&hist, sizeof(long long) * HSZ * (size_t)NL); hipMalloc((void**)&d_sum, sizeof(long long) * 2);
   hipMalloc((void**)&d_mx, sizeof(unsigned long long) * 2); hipMalloc((void**)&d_used, F);
   hipMalloc((void**)&d_split, sizeof(SplitInfo) * 2);
+  hipMalloc((void**)&d_featbest, sizeof(SplitInfo) * 2 * (size_t)F); hipMalloc((void**)&d_done, sizeof(unsigned));
+  if (d_done) hipMemsetAsync(d_done, 0, sizeof(unsigned), st);
   hipMalloc((void**)&d_feat, sizeof(int) * NL); hipMalloc((void**)&d_bin, sizeof(int) * NL);
   hipMalloc((void**)&d_lc, sizeof(int) * NL); hipMalloc((void**)&d_rc, sizeof(int) * NL); hipMalloc((void**)&d_leafv, sizeof(double) * NL);
   if (hipGetLastError() != hipSuccess || !d_cur || !d_leafv) { rihip_set_error("lambdamart_train: device allocation failed"); return RIHIP_ERR_HIP; }
@@ -707,24 +772,22 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
     TCHK(hipMemsetAsync(dst, 0, sizeof(long long) * HSZ, st));
     if (len <= 0) return RIHIP_OK;
     const unsigned nchunk = (unsigned)((len + HCH - 1) / HCH);
-    const int fch = wide ? FCH / 2 : FCH;     // the same 150 KB of LDS with 8-byte cells
-    for (int f0 = 0; f0 < F; f0 += fch) {
-      const int nf = std::min(fch, F - f0);
-      if (wide)
-        hipLaunchKernelGGL(hist_kernel<long long>, dim3(nchunk), dim3(256), (size_t)nf * NBIN * 3 * 8, st, T.Xb, F, rows, b0, len,
-                           (const long long*)gq, (const long long*)hq, f0, nf, dst);
-      else
-        hipLaunchKernelGGL(hist_kernel<int>, dim3(nchunk), dim3(256), (size_t)nf * NBIN * 3 * 4, st, T.Xb, F, rows, b0, len,
-                           (const int*)gq, (const int*)hq, f0, nf, dst);
-    }
+    const int fch = wide ? FCH / 2 : FCH;     // the same 30 KB of LDS with 8-byte cells
+    const dim3 grid(nchunk, (unsigned)((F + fch - 1) / fch));
+    if (wide)
+      hipLaunchKernelGGL(hist_kernel<long long>, grid, dim3(256), (size_t)fch * NBIN * 3 * 8, st, T.Xb, F, rows, b0, len,
+                         (const long long*)gq, (const long long*)hq, fch, dst);
+    else
+      hipLaunchKernelGGL(hist_kernel<int>, grid, dim3(256), (size_t)fch * NBIN * 3 * 4, st, T.Xb, F, rows, b0, len,
+                         (const int*)gq, (const int*)hq, fch, dst);
     TCHK(hipGetLastError());
     return RIHIP_OK;
   };
   double sg = 0.0, sh = 0.0;
   // best splits of up to two leaves (the children of a split) in one launch; a null histogram = leaf not tried
   auto find_splits = [&](const long long* h0, const long long* h1, SplitInfo* slots) {
-    hipLaunchKernelGGL(split_kernel, dim3(h1 ? 2 : 1), dim3(1024), 0, st, h0, h1, F, d_nb, d_nanbin, d_used, sg, sh, p->reg_alpha,
-                       p->reg_lambda, p->min_child_samples, p->min_sum_hessian, split_order, slots, (const long long*)nullptr, -1);
+    hipLaunchKernelGGL(split_kernel, dim3((unsigned)((F + 3) / 4), h1 ? 2 : 1), dim3(256), 0, st, h0, h1, F, d_nb, d_nanbin, d_used, sg, sh, p->reg_alpha,
+                       p->reg_lambda, p->min_child_samples, p->min_sum_hessian, split_order, slots, (const long long*)nullptr, -1, d_featbest, d_done);
   };
   SplitInfo* h_split = nullptr;   // pinned: the per-split read-back is on the critical path of the tree growth
   if (hipHostMalloc((void**)&h_split, sizeof(SplitInfo) * 2) != hipSuccess) h_split = nullptr;
@@ -765,7 +828,7 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
     // ---- gradients
     hipLaunchKernelGGL(lambdarank_kernel, dim3(ng), dim3(256), grad_lds, st, ga);
     hipMemsetAsync(d_mx, 0, sizeof(unsigned long long) * 2, st);
-    hipLaunchKernelGGL(unsort_absmax_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ls, hs, T.sorted, n, lam, hes, d_mx);
+    hipLaunchKernelGGL(unsort_absmax_kernel, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, st, ls, hs, T.sorted, n, lam, hes, d_mx);
     unsigned long long mxb[2];
     if (hipMemcpyAsync(mxb, d_mx, sizeof(mxb), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rihip_set_error("lambdamart_train: gradient pass failed: %s", hipGetErrorString(hipGetLastError())); rc = RIHIP_ERR_HIP; break; }
     double gm, hm; memcpy(&gm, &mxb[0], 8); memcpy(&hm, &mxb[1], 8);
@@ -876,8 +939,8 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
         // parent's slot); a larger child that is not tried is a final leaf: its histogram is never read again
         const long long* hS = hist + (size_t)S.slot * HSZ;
         const int big_child = left_small ? 1 : 0;
-        hipLaunchKernelGGL(split_kernel, dim3(tryR ? 2 : 1), dim3(1024), 0, st, hL, hR, F, d_nb, d_nanbin, d_used, sg, sh, p->reg_alpha,
-                           p->reg_lambda, p->min_child_samples, p->min_sum_hessian, split_order, d_split, hS, big_child);
+        hipLaunchKernelGGL(split_kernel, dim3((unsigned)((F + 3) / 4), tryR ? 2 : 1), dim3(256), 0, st, hL, hR, F, d_nb, d_nanbin, d_used, sg, sh, p->reg_alpha,
+                           p->reg_lambda, p->min_child_samples, p->min_sum_hessian, split_order, d_split, hS, big_child, d_featbest, d_done);
         rc = read_splits(two, 2);
         if (rc) break;
       }
@@ -918,7 +981,7 @@ extern "C" int rihip_lambdamart_train(const float* X, const float* y, const int3
   }
   hipStreamSynchronize(st);
   hipFree(ls); hipFree(hs); hipFree(lam); hipFree(hes); hipFree(gq); hipFree(hq); hipFree(rowsA); hipFree(rowsB); hipFree(d_cur);
-  hipFree(hist); hipFree(d_sum); hipFree(d_mx); hipFree(d_used); hipFree(d_split);
+  hipFree(hist); hipFree(d_sum); hipFree(d_mx); hipFree(d_used); hipFree(d_split); hipFree(d_featbest); hipFree(d_done);
   if (h_split) hipHostFree(h_split);
   hipFree(d_feat); hipFree(d_bin); hipFree(d_lc); hipFree(d_rc); hipFree(d_leafv);
   T.release(); V.release(); hipFree(d_ub); hipFree(d_nb); hipFree(d_nanbin); hipFree(d_gain); hipFree(d_ks);
