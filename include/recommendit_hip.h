@@ -351,6 +351,19 @@ int rihip_ip_index_set_nprobe(void* handle, int nprobe);
 int rihip_ip_index_set_two_precision(void* handle, int enable);
 int rihip_ip_index_search(void* handle, const float* Q, int64_t nq, int k, float* out_scores, int64_t* out_rows,
                           void* stream);
+/* Deferred exactness check for serving chains (the reference's recommender.py:269-387 runs retrieval -> features ->
+ * ranker per request; here the chain is enqueued without a host round trip in its middle): with enable = 1 a thresholded
+ * IVF search of <= 4096 queries returns WITHOUT the host synchronisation that reads how many queries need the exact
+ * re-do; enqueue the consumers of the result, then call rihip_ip_index_search_finish (one synchronisation): *n_redone > 0
+ * means that many queries were re-done exactly into the same output rows after the consumers ran -- run them again.
+ * finish must be called before the next search of the handle; all other search paths are unaffected (*n_redone = 0). */
+int rihip_ip_index_set_deferred_check(void* handle, int enable);
+int rihip_ip_index_search_finish(void* handle, int* n_redone, void* stream);
+/* for hipGraph replays of a captured chain (no host code runs inside a replay): _pending = 1 while a deferred search
+ * awaits its finish (ask right after capture); _last_fail_count synchronises `stream` and returns the failure count the
+ * last enqueued deferred search wrote -- n > 0: run the chain again eagerly with the check not deferred */
+int rihip_ip_index_search_pending(void* handle);
+int rihip_ip_index_last_fail_count(void* handle, int* n, void* stream);
 int rihip_ip_index_save(void* handle, const char* path);          /* host path; synchronous */
 int rihip_ip_index_load(const char* path, void** handle);         /* host path; synchronous */
 /* rows[i] = rows[i] >= 0 ? item_ids[rows[i]] : -1   (faiss_index.py:123, :148-152) */

@@ -102,6 +102,10 @@ SIGNATURES = {
     "rihip_ip_index_set_nprobe": (C.c_int, [vp, C.c_int]),
     "rihip_ip_index_set_two_precision": (C.c_int, [vp, C.c_int]),
     "rihip_ip_index_search": (C.c_int, [vp, vp, c_i64, C.c_int, vp, vp, vp]),
+    "rihip_ip_index_set_deferred_check": (C.c_int, [vp, C.c_int]),
+    "rihip_ip_index_search_finish": (C.c_int, [vp, vp, vp]),
+    "rihip_ip_index_search_pending": (C.c_int, [vp]),
+    "rihip_ip_index_last_fail_count": (C.c_int, [vp, vp, vp]),
     "rihip_ip_index_save": (C.c_int, [vp, C.c_char_p]),
     "rihip_ip_index_load": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
     "rihip_map_rows_to_ids": (C.c_int, [vp, c_i64, vp, vp]),

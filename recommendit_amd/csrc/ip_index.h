@@ -58,6 +58,14 @@ struct IpIndex {
   DevBuf<float> coarse;                                    // IVF: coarse scores [nq,nlist]
   DevBuf<int> probe_list, list_q, list_cnt, list_qoff, list_cur, work_off, plan;
   int* h_nfail = nullptr;  // pinned
+  // deferred exactness check (rihip_ip_index_set_deferred_check): a thresholded IVF search of at most one internal chunk
+  // returns without its host synchronisation; rihip_ip_index_search_finish() reads the failure count and re-does the
+  // failed queries (unfiltered pass) into the same output rows
+  bool defer_check = false, defer_ok = false;
+  struct { bool active = false; const float* Q = nullptr; int64_t nq = 0; int k = 0; float* out_s = nullptr; int64_t* out_r = nullptr; } pending;
+  const int* redo_slots = nullptr;   // internal: search_chunk runs only the unfiltered IVF pass, results to these rows
+  hipEvent_t ev_fail = nullptr;      // recorded behind the failure count's copy of a deferred search (not while capturing)
+  bool ev_recorded = false;
 };
 
 inline void free_index_arrays(IpIndex* h) {

@@ -1996,6 +1996,7 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
       RCCHK(launch_finalize(f2, (unsigned)n, st));
       return check_launch("finalize");
     };
+    if (h->redo_slots) return ivf_full(Q, nq, h->redo_slots);   // (rihip_ip_index_search_finish: the exact re-do only)
     const int SS = 16;  // threshold sample: every 16th probed tile
     // small populations or small batches (single requests): the unfiltered pass needs no threshold sample, no
     // exactness check and no host sync
@@ -2024,6 +2025,20 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
     hipLaunchKernelGGL(collect_fail_kernel, dim3(nqb), dim3(256), 0, st, h->fail_flags.p, nq, h->fail_list.p, h->n_fail.p);
     RCCHK(check_launch("finalize"));
     HIPCHK(hipMemcpyAsync(h->h_nfail, h->n_fail.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (h->defer_check && h->defer_ok) {   // the caller checks later (rihip_ip_index_search_finish): no host sync here
+      // finish then waits for THIS point of the stream only: whatever the caller enqueues behind the search keeps the GPU
+      // busy while the host is already back (a capturing stream records no event: replays use _last_fail_count)
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      (void)hipStreamIsCapturing(st, &cs);
+      h->ev_recorded = false;
+      if (cs == hipStreamCaptureStatusNone) {
+        if (!h->ev_fail) HIPCHK(hipEventCreateWithFlags(&h->ev_fail, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(h->ev_fail, st));
+        h->ev_recorded = true;
+      }
+      h->pending.active = true; h->pending.Q = Q; h->pending.nq = nq; h->pending.k = k; h->pending.out_s = out_s; h->pending.out_r = out_r;
+      return RIHIP_OK;
+    }
     HIPCHK(hipStreamSynchronize(st));
     const int nf = *h->h_nfail;
     if (nf > 0) {  // threshold too aggressive (or candidate overflow) for these queries: unfiltered re-do
@@ -2310,6 +2325,7 @@ extern "C" int rihip_ip_index_destroy(void* handle) {
   h->list_cur.release(); h->work_off.release(); h->plan.release(); h->qnorm.release(); h->seg.release(); h->seg_cnt.release();
   h->qpad.release();
   if (h->h_nfail) hipHostFree(h->h_nfail);
+  if (h->ev_fail) (void)hipEventDestroy(h->ev_fail);
   delete h;
   return RIHIP_OK;
 }
@@ -2378,11 +2394,63 @@ extern "C" int rihip_ip_index_search(void* handle, const float* Q, int64_t nq, i
   }
   RIHIP_REQUIRE((reinterpret_cast<uintptr_t>(Q) & 15) == 0, RIHIP_ERR_ARG, "ip_index_search: Q must be 16-byte aligned");
   const int64_t CH = 4096;  // queries per internal pass (bounds scratch)
+  h->pending.active = false;
+  h->defer_ok = nq <= CH;
   for (int64_t q0 = 0; q0 < nq; q0 += CH) {
     const int64_t n = (nq - q0 < CH) ? nq - q0 : CH;
     int rc = search_chunk(h, Q + q0 * h->d, n, k, out_scores + q0 * k, out_rows + q0 * k, (hipStream_t)stream);
     if (rc) return rc;
   }
+  return RIHIP_OK;
+}
+
+// Deferred exactness check (serving chains): with enable = 1 a thresholded IVF search of <= 4 096 queries enqueues its
+// work and returns WITHOUT the host synchronisation that reads the count of queries whose candidate threshold was too
+// aggressive; the caller enqueues whatever consumes the results, then calls rihip_ip_index_search_finish (one sync):
+// n_redone > 0 means that many queries were re-done exactly into the same output rows AFTER the consumers ran -- run them
+// again.  finish must be called before the next search of the handle.  Other search paths are unaffected (n_redone = 0).
+extern "C" int rihip_ip_index_set_deferred_check(void* handle, int enable) {
+  IpIndex* h = (IpIndex*)handle;
+  RIHIP_REQUIRE(h, RIHIP_ERR_ARG, "ip_index_set_deferred_check: null handle");
+  h->defer_check = enable != 0;
+  h->pending.active = false;   // (also drops a pending check: what a caller does after CAPTURING a chain, which ran nothing)
+  return RIHIP_OK;
+}
+// 1 while a deferred search awaits its finish (what a hipGraph capture of a chain needs to know about itself)
+extern "C" int rihip_ip_index_search_pending(void* handle) { return handle && ((IpIndex*)handle)->pending.active ? 1 : 0; }
+// The failure count the LAST enqueued deferred search wrote (after a synchronisation of `stream`): for replays of a
+// captured chain, which run no host code -- n > 0: run the chain again eagerly, not deferred.
+extern "C" int rihip_ip_index_last_fail_count(void* handle, int* n, void* stream) {
+  IpIndex* h = (IpIndex*)handle;
+  RIHIP_REQUIRE(h && n && h->h_nfail, RIHIP_ERR_ARG, "ip_index_last_fail_count: no deferred search has run");
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  *n = *h->h_nfail;
+  return RIHIP_OK;
+}
+extern "C" int rihip_ip_index_search_finish(void* handle, int* n_redone, void* stream) {
+  IpIndex* h = (IpIndex*)handle;
+  RIHIP_REQUIRE(h && n_redone, RIHIP_ERR_ARG, "ip_index_search_finish: bad arguments");
+  *n_redone = 0;
+  if (!h->pending.active) return RIHIP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  h->pending.active = false;
+  if (h->ev_recorded) HIPCHK(hipEventSynchronize(h->ev_fail));
+  else HIPCHK(hipStreamSynchronize(st));
+  const int nf = *h->h_nfail;
+  if (nf <= 0) return RIHIP_OK;
+  const int FCH = 64, d = h->d;
+  RCCHK(h->fQ.reserve((int64_t)FCH * d));
+  for (int f0 = 0; f0 < nf; f0 += FCH) {
+    const int nfc = (nf - f0 < FCH) ? nf - f0 : FCH;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((nfc * d + 255) / 256)), dim3(256), 0, st, h->pending.Q,
+                       h->fail_list.p + f0, nfc, d, h->fQ.p);
+    h->redo_slots = h->fail_list.p + f0;
+    const int rc = search_chunk(h, h->fQ.p, nfc, h->pending.k, h->pending.out_s, h->pending.out_r, st);
+    h->redo_slots = nullptr;
+    if (rc) return rc;
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  *n_redone = nf;
   return RIHIP_OK;
 }
 

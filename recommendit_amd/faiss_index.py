@@ -170,6 +170,27 @@ class FAISSIndex:
                                           L.stream_ptr()), "ip_index_search")
         return scores, rows
 
+    def set_deferred_check(self, enable: bool) -> None:
+        """Serving chains (not in the reference): a thresholded IVF search then returns without its host
+        synchronisation; call `finish_search()` after enqueueing the consumers of the result."""
+        L.check(L.lib().rihip_ip_index_set_deferred_check(self.index._h, 1 if enable else 0), "ip_index_set_deferred_check")
+
+    def finish_search(self) -> int:
+        """-> number of queries of the last deferred search that had to be re-done exactly (their output rows were
+        rewritten AFTER anything enqueued behind the search ran: run those consumers again); 0 almost always."""
+        n = C.c_int(0)
+        L.check(L.lib().rihip_ip_index_search_finish(self.index._h, C.byref(n), L.stream_ptr()), "ip_index_search_finish")
+        return int(n.value)
+
+    def search_pending(self) -> bool:
+        return bool(L.lib().rihip_ip_index_search_pending(self.index._h))
+
+    def last_fail_count(self) -> int:
+        """after the REPLAY of a captured chain that holds a deferred search: synchronises, -> its failure count"""
+        n = C.c_int(0)
+        L.check(L.lib().rihip_ip_index_last_fail_count(self.index._h, C.byref(n), L.stream_ptr()), "ip_index_last_fail_count")
+        return int(n.value)
+
     def search(self, query_vector: np.ndarray, k: int = 500) -> Tuple[np.ndarray, np.ndarray]:
         if self.index is None:
             raise RuntimeError("Index not built. Call build_ivf_index() first.")

@@ -9,6 +9,8 @@ the caller for single requests (drop-in through the three model classes); this m
 """
 from __future__ import annotations
 
+import os
+
 from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -168,6 +170,7 @@ class GpuRecommendationPipeline:
         self.model, self.index, self.ranker, self.store = model, index, ranker, store
         self.top_k_candidates, self.top_k_results = top_k_candidates, top_k_results
         self._graphs: Dict[Tuple[int, int], Any] = {}
+        self._defer = os.environ.get("RIHIP_SERVE_DEFER", "1") != "0"   # 0: exactness check inside the search (experiments)
 
     @torch.no_grad()
     def recommend_batch(self, user_ids, k: Optional[int] = None, graph: bool = False
@@ -179,14 +182,34 @@ class GpuRecommendationPipeline:
         graph=True (small request batches): the ~20 launches of the chain are captured once per (batch size, k) into a
         hipGraph and replayed -- a single request is launch-bound otherwise.  The returned tensors are the graph's static
         outputs: valid until the next replay of the same shape.  Falls back to the eager chain when the shape takes a
-        path with a host synchronisation (large batches: the thresholded IVF scan checks exactness on the host)."""
+        path with a host synchronisation inside the chain."""
         k = k or self.top_k_results
-        if graph:
-            out = self._replay(user_ids, k)
+        # The retrieval stage's exactness check is deferred to the END of the chain (FAISSIndex.set_deferred_check): the
+        # thresholded IVF pass of a large batch used to stop for a host round trip in the middle of the chain (a 54 us
+        # hole at 256 requests, and the reason such batches could not be captured as a hipGraph).  In the rare case that
+        # queries had to be re-done exactly, the chain runs again on the corrected candidates (not deferred).
+        if not self._defer:
+            out = self._replay(user_ids, k) if graph else None
             if out is not None:
-                return out
-        uid = torch.as_tensor(user_ids, dtype=torch.long, device=L.device())
-        return self._chain(uid, k)
+                return out[0]
+            return self._chain(torch.as_tensor(user_ids, dtype=torch.long, device=L.device()), k)
+        self.index.set_deferred_check(True)
+        try:
+            out = self._replay(user_ids, k) if graph else None
+            uid = None
+            if out is not None:
+                out, redone = out
+            else:
+                uid = torch.as_tensor(user_ids, dtype=torch.long, device=L.device())
+                out = self._chain(uid, k)
+                redone = self.index.finish_search()
+        finally:
+            self.index.set_deferred_check(False)
+        if redone:
+            if uid is None:
+                uid = torch.as_tensor(user_ids, dtype=torch.long, device=L.device())
+            out = self._chain(uid, k)
+        return out
 
     def _graph_state(self):
         """everything a captured chain bakes in besides the torch-owned tensors of its own pool: the library's scratch
@@ -215,22 +238,26 @@ class GpuRecommendationPipeline:
                 with torch.cuda.stream(side):      # warm-up: scratch buffers, LDS grants, lazy module loads
                     for _ in range(2):
                         self._chain(su, k)
+                        self.index.finish_search()
                 cur.wait_stream(side)
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     out = self._chain(su, k)
-                ent = (g, su, out, self._graph_state())     # recorded AFTER capture: the warm-up may have grown scratch
+                deferred = self.index.search_pending()      # the captured search left its exactness check to the caller
+                self.index.set_deferred_check(True)         # (capture ran nothing: drop the pending state)
+                ent = (g, su, out, self._graph_state(), deferred)   # state recorded AFTER capture: the warm-up may have grown scratch
             except Exception:                        # a path with a host sync cannot be captured: stay eager for this shape
                 torch.cuda.synchronize()
                 ent = False
             self._graphs[key] = ent
         if ent is False:
             return None
-        g, su, out, _ = ent
+        g, su, out, _, deferred = ent
         su.copy_(torch.as_tensor(user_ids, dtype=torch.long), non_blocking=True)
         g.replay()
-        return out
+        # a replay runs no host code: the failure count of its deferred search is read here (one synchronisation)
+        return out, (self.index.last_fail_count() if deferred else 0)
 
     def _chain(self, uid: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         q = self.model.get_user_embeddings(uid, as_tensor=True)

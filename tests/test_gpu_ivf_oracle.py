@@ -317,3 +317,39 @@ def test_rank_topk_large_candidate_sets_and_nan_scores():
             np.testing.assert_array_equal(ids[q], cand[q][order])
             if k < kc - 4:
                 assert not np.isnan(top[q]).any()
+
+
+def test_deferred_exactness_check_equals_the_synchronous_search():
+    """Serving chains defer the thresholded IVF pass's exactness check to their end (`set_deferred_check` /
+    `finish_search`): the deferred search + finish must give what the synchronous search gives, including for queries
+    that take the exact re-do (here: 6 000 identical rows tie at the threshold and overflow the candidate lists)."""
+    from recommendit_amd import FAISSIndex
+    rng = np.random.RandomState(5)
+    N, d, nq, k = 300_000, 128, 600, 500
+    X = fx.unit_rows(rng, N, d)
+    X[:6000] = X[0]
+    Q = fx.unit_rows(rng, nq, d)
+    Q[:40] = X[0] + 0.01 * rng.randn(40, d).astype(np.float32)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    idx = FAISSIndex(embed_dim=d, n_lists=100, n_probe=10)
+    idx.build_from_device(torch.from_numpy(X).cuda(), np.arange(N))
+    q = torch.from_numpy(Q).cuda()
+    s0, r0 = idx.batch_search_device(q, k=k, normalized=True)            # synchronous check + re-do inside
+    idx.set_deferred_check(True)
+    s1, r1 = idx.batch_search_device(q, k=k, normalized=True)
+    assert idx.search_pending()
+    n = idx.finish_search()
+    idx.set_deferred_check(False)
+    assert n >= 40, n                                                     # the tied queries were re-done
+    assert not idx.search_pending()
+    torch.testing.assert_close(r1, r0, rtol=0, atol=0)
+    torch.testing.assert_close(s1, s0, rtol=0, atol=0)
+    # a batch of random queries (few or no re-dos): same results
+    qb = torch.from_numpy(fx.unit_rows(rng, nq, d)).cuda()
+    s2, r2 = idx.batch_search_device(qb, k=k, normalized=True)
+    idx.set_deferred_check(True)
+    s3, r3 = idx.batch_search_device(qb, k=k, normalized=True)
+    assert idx.finish_search() < 40
+    idx.set_deferred_check(False)
+    torch.testing.assert_close(r3, r2, rtol=0, atol=0)
+    torch.testing.assert_close(s3, s2, rtol=0, atol=0)
