@@ -170,6 +170,7 @@ class GpuRecommendationPipeline:
         self.model, self.index, self.ranker, self.store = model, index, ranker, store
         self.top_k_candidates, self.top_k_results = top_k_candidates, top_k_results
         self._graphs: Dict[Tuple[int, int], Any] = {}
+        self._pin: Dict[int, Any] = {}
         self._defer = os.environ.get("RIHIP_SERVE_DEFER", "1") != "0"   # 0: exactness check inside the search (experiments)
 
     @torch.no_grad()
@@ -192,7 +193,7 @@ class GpuRecommendationPipeline:
             out = self._replay(user_ids, k) if graph else None
             if out is not None:
                 return out[0]
-            return self._chain(torch.as_tensor(user_ids, dtype=torch.long, device=L.device()), k)
+            return self._chain(self._ids_to_device(user_ids), k)
         self.index.set_deferred_check(True)
         try:
             out = self._replay(user_ids, k) if graph else None
@@ -200,16 +201,36 @@ class GpuRecommendationPipeline:
             if out is not None:
                 out, redone = out
             else:
-                uid = torch.as_tensor(user_ids, dtype=torch.long, device=L.device())
+                uid = self._ids_to_device(user_ids)
                 out = self._chain(uid, k)
                 redone = self.index.finish_search()
         finally:
             self.index.set_deferred_check(False)
         if redone:
             if uid is None:
-                uid = torch.as_tensor(user_ids, dtype=torch.long, device=L.device())
+                uid = self._ids_to_device(user_ids)
             out = self._chain(uid, k)
         return out
+
+    def _ids_to_device(self, user_ids) -> torch.Tensor:
+        """user ids -> device without stalling the host: `torch.as_tensor(list, device=...)` is a pageable copy, which
+        blocks the host until everything already enqueued on the stream (the previous batch's chain) has run -- a 0.1 ms
+        hole per 256-request batch.  A pinned staging buffer per batch size + an asynchronous copy lets the host enqueue
+        batch k+1 while the GPU still works on batch k."""
+        if isinstance(user_ids, torch.Tensor) and user_ids.is_cuda:
+            return user_ids.to(dtype=torch.long)
+        n = len(user_ids)
+        ent = self._pin.get(n)
+        if ent is None:
+            ent = (torch.empty((n,), dtype=torch.long).pin_memory(), torch.empty((n,), dtype=torch.long, device=L.device()),
+                   torch.cuda.Event())
+            self._pin[n] = ent
+        pin, dev_t, ev = ent
+        ev.synchronize()                        # the previous copy out of the staging buffer has executed
+        pin.copy_(torch.as_tensor(user_ids, dtype=torch.long))
+        dev_t.copy_(pin, non_blocking=True)
+        ev.record()
+        return dev_t
 
     def _graph_state(self):
         """everything a captured chain bakes in besides the torch-owned tensors of its own pool: the library's scratch
