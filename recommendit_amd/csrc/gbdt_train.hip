@@ -148,6 +148,9 @@ __global__ __launch_bounds__(256) void lambdarank_kernel(GradArgs a) {
   double li[MAX_T], hi[MAX_T];   // this thread's share of lambda_i / hessian_i, i < truncation level
 #pragma unroll
   for (int i = 0; i < MAX_T; ++i) { li[i] = 0.0; hi[i] = 0.0; }
+  __shared__ double disc[MAX_T];   // 1 / log2(i + 2) of the truncation positions (the same expression as for the partner r)
+  if (tid < MAX_T) disc[tid] = 1.0 / log2((double)tid + 2.0);
+  __syncthreads();
   double sum_l = 0.0;
   for (int r = tid; r < cnt; r += 256) {
     const double sr = ss[r];
@@ -155,24 +158,28 @@ __global__ __launch_bounds__(256) void lambdarank_kernel(GradArgs a) {
     const double gr = a.gain_tab[lr], dr = 1.0 / log2((double)r + 2.0);
     double lam_r = 0.0, hes_r = 0.0;
     const int iend = r < ni ? r : ni;
-#pragma unroll 1
-    for (int i = 0; i < iend; ++i) {           // pair (i, r), i ranked above r
-      const int lab_i = ll[i];
-      if (lab_i == lr) continue;
-      const bool hi_is_i = lab_i > lr;
-      const double si = ss[i];
-      const double ds = hi_is_i ? si - sr : sr - si;
-      double dn = fabs(a.gain_tab[lab_i] - gr) * fabs(1.0 / log2((double)i + 2.0) - dr) * inv;
-      if (do_norm) dn = dn / (0.01 + fabs(ds));
-      const double rho = 1.0 / (1.0 + exp(a.sigmoid * ds));
-      const double pl = -a.sigmoid * dn * rho;
-      const double ph = a.sigmoid * a.sigmoid * dn * rho * (1.0 - rho);
-      lam_r += hi_is_i ? -pl : pl;
-      hes_r += ph;
+    // The loop over the truncation positions is unrolled with a STATIC index: every lane is at the same i in the same
+    // iteration, so li[i] / hi[i] are plain registers (a dynamic index cost a 32-way select of two doubles per pair);
+    // the order of the additions is the one of the rolled loop (i ascending), so the sums are bit for bit the same.
 #pragma unroll
-      for (int k = 0; k < MAX_T; ++k)           // static register index: select, do not index dynamically
-        if (k == i) { li[k] += hi_is_i ? pl : -pl; hi[k] += ph; }
-      sum_l += -2.0 * pl;
+    for (int i = 0; i < MAX_T; ++i) {           // pair (i, r), i ranked above r
+      if (i < iend) {
+        const int lab_i = ll[i];
+        if (lab_i != lr) {
+          const bool hi_is_i = lab_i > lr;
+          const double si = ss[i];
+          const double ds = hi_is_i ? si - sr : sr - si;
+          double dn = fabs(a.gain_tab[lab_i] - gr) * fabs(disc[i] - dr) * inv;
+          if (do_norm) dn = dn / (0.01 + fabs(ds));
+          const double rho = 1.0 / (1.0 + exp(a.sigmoid * ds));
+          const double pl = -a.sigmoid * dn * rho;
+          const double ph = a.sigmoid * a.sigmoid * dn * rho * (1.0 - rho);
+          lam_r += hi_is_i ? -pl : pl;
+          hes_r += ph;
+          li[i] += hi_is_i ? pl : -pl; hi[i] += ph;
+          sum_l += -2.0 * pl;
+        }
+      }
     }
     a.lam[b + r] = lam_r;                       // rank-order scratch; positions < ni are completed below
     a.hes[b + r] = hes_r;
