@@ -1015,6 +1015,7 @@ struct FinArgs {
   const float* ivf_thr;
   const int64_t* id_map;  // optional: out_rows[i] = id_map[row] (the wrapper's faiss index -> item id), or null
   int* zero_me;           // optional: one int this launch resets (the failed-query counter of the kernels that follow)
+  int* fail_list; int* n_fail;   // optional (mode 0): a failed query appends itself here (n_fail reset by an earlier launch's zero_me)
   int lds_keys;           // > 0: key slots in dynamic LDS behind the sort buffer (set by launch_finalize for small launches)
   int sort_slots;         // uint64 slots of the sort buffer in front of them
 };
@@ -1182,6 +1183,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs a) {
     if (sk < a.thr_chk[q] + a.eps_scale * a.qnorm[q] + 2e-6f) fail = true;
   }
   if (a.fail_flags && tid == 0) a.fail_flags[q] = fail ? 1 : 0;
+  if (fail && a.fail_list && tid == 0) a.fail_list[atomicAdd(a.n_fail, 1)] = (int)q;   // (order immaterial: each is re-done on its own)
   if (a.out_keys) {
     for (int i = tid; i < a.k; i += 256) a.out_keys[oslot * a.k + i] = i < k_sel ? sbuf[i] : 0ull;
     return;
@@ -2014,15 +2016,16 @@ int search_chunk(IpIndex* h, const float* Q, int64_t nq, int k, float* out_s, in
     RCCHK(h->cand.reserve(nq * cap));
     RCCHK(ivf_prepare(Q, nq, SS, h->scand.p, nq * cap_s));      // (also zeroes the sample's dense slots: key 0 = below every score)
     RCCHK(ivf_scan(Q, nq, nullptr, h->scand.p, cap_s, SS, cap_l, true, 0));
-    hipLaunchKernelGGL(fill_int_kernel, dim3(nqb), dim3(256), 0, st, h->count.p, nq, (int)cap_s);
-    fa.cand = h->scand.p; fa.cap = cap_s; fa.mode = 1; fa.rank = rank; fa.thr_out = h->thr.p;
+    // (the sample's lists are dense: count = null means cap_s keys each; this launch also resets the failed-query counter
+    // that the final select appends to -- no fill / collect launches of their own)
+    fa.cand = h->scand.p; fa.cap = cap_s; fa.mode = 1; fa.rank = rank; fa.thr_out = h->thr.p; fa.count = nullptr;
+    fa.zero_me = h->n_fail.p;
     RCCHK(launch_finalize(fa, (unsigned)nq, st));
     RCCHK(ivf_scan(Q, nq, h->thr.p, h->cand.p, cap, 1, 0, false, 0));                         // pass B: all probed tiles, filtered
     fa.cand = h->cand.p; fa.cap = cap; fa.mode = 0; fa.thr_out = nullptr; fa.fail_flags = h->fail_flags.p;
+    fa.count = h->count.p; fa.zero_me = nullptr; fa.fail_list = h->fail_list.p; fa.n_fail = h->n_fail.p;
     fa.ivf_thr = h->thr.p; fa.count_stride = CSTRIDE;
     RCCHK(launch_finalize(fa, (unsigned)nq, st));
-    hipLaunchKernelGGL(fill_int_kernel, dim3(1), dim3(64), 0, st, h->n_fail.p, 1, 0);
-    hipLaunchKernelGGL(collect_fail_kernel, dim3(nqb), dim3(256), 0, st, h->fail_flags.p, nq, h->fail_list.p, h->n_fail.p);
     RCCHK(check_launch("finalize"));
     HIPCHK(hipMemcpyAsync(h->h_nfail, h->n_fail.p, sizeof(int), hipMemcpyDeviceToHost, st));
     if (h->defer_check && h->defer_ok) {   // the caller checks later (rihip_ip_index_search_finish): no host sync here
